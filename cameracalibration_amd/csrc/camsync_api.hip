@@ -1,0 +1,975 @@
+// camsync_api.hip — the extern "C" boundary of libcamsync_hip.so
+// (include/camsync.h).  Owns the context: one HIP stream, the scratch lists of
+// the detection pipeline sized for max_batch frames, the dictionary and the
+// cornerSubPix weight table, the calibration state.  Batches larger than
+// max_batch are processed in chunks on the same stream.
+#include "internal.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+#include <string>
+#include <vector>
+
+using namespace camsync;
+
+struct camsync_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int maxH = 0, maxW = 0, maxB = 0;
+    camsync_params params;
+    int dictN = 0, markerSize = 4, maxCorrectionBits = 1;
+    std::string err;
+
+    // device scratch
+    uint8_t* d_in = nullptr;
+    size_t inBytes = 0;
+    DetBuffers buf{};
+    uint16_t* d_dict = nullptr;
+    float* d_expTab = nullptr;
+    // pose scratch
+    float *d_obj = nullptr, *d_img = nullptr;
+    int32_t* d_npts = nullptr;
+    double *d_K = nullptr, *d_dist = nullptr, *d_rvec = nullptr, *d_tvec = nullptr, *d_mae = nullptr, *d_rmse = nullptr;
+    uint8_t* d_ok = nullptr;
+    int32_t* d_anchorIds = nullptr;
+    float* d_anchorObj = nullptr;
+    size_t poseCap = 0;  // frames the pose scratch is sized for
+    int poseN = 0;
+
+    // last detect chunk (for the debug getters)
+    int lastB = 0, lastH = 0, lastW = 0;
+
+    // calibration
+    CalibState cal{};
+    float *d_calObj = nullptr, *d_calImg = nullptr;
+    double* d_calDelta = nullptr;
+    double* d_focalRows = nullptr;
+    double* d_focalAcc = nullptr;
+    uint8_t* d_calOk = nullptr;
+    double* d_calK = nullptr;
+    int32_t* d_calNpts = nullptr;
+    bool calReady = false;
+
+    // timers
+    bool timing = false;
+    hipEvent_t ev[CAMSYNC_N_STAGES + 1] = {};
+    double ms[CAMSYNC_N_STAGES] = {};
+    int64_t launches[CAMSYNC_N_STAGES] = {};
+};
+
+namespace {
+
+int fail(camsync_ctx* c, int code, const char* fmt, ...) {
+    if (c) {
+        char tmp[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(tmp, sizeof tmp, fmt, ap);
+        va_end(ap);
+        c->err = tmp;
+    }
+    return code;
+}
+
+#define HIPCHK(c, call)                                                                          \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess) return fail(c, CAMSYNC_E_HIP, "%s: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+template <class T>
+hipError_t dalloc(T** p, size_t n) {
+    return hipMalloc(reinterpret_cast<void**>(p), std::max<size_t>(n, 1) * sizeof(T));
+}
+
+// DICT_4X4_50 codes are supplied by the caller (camsync_set_dictionary); the
+// Python mirror ships the table (camera_sync/_dict4x4_50.py).
+
+DetCfg make_cfg(const camsync_ctx* c, int H, int W) {
+    const camsync_params& p = c->params;
+    DetCfg g{};
+    g.H = H;
+    g.W = W;
+    g.nScales = (p.adaptiveThreshWinSizeMax - p.adaptiveThreshWinSizeMin) / p.adaptiveThreshWinSizeStep + 1;
+    g.nScales = std::min(g.nScales, kMaxScales);
+    for (int i = 0; i < g.nScales; i++) {
+        int win = p.adaptiveThreshWinSizeMin + i * p.adaptiveThreshWinSizeStep;
+        if (win % 2 == 0) win++;
+        g.radius[i] = win / 2;
+    }
+    g.idelta = (int)floor(p.adaptiveThreshConstant);
+    const int maxdim = std::max(W, H);
+    g.minPerim = (int)(unsigned)(p.minMarkerPerimeterRate * maxdim);
+    g.maxPerim = (int)(unsigned)(p.maxMarkerPerimeterRate * maxdim);
+    g.accuracyRate = p.polygonalApproxAccuracyRate;
+    g.minCornerDistanceRate = p.minCornerDistanceRate;
+    g.minDistToBorder = p.minDistanceToBorder;
+    g.borderBits = p.markerBorderBits;
+    g.markerSize = c->markerSize;
+    g.cellSize = p.perspectiveRemovePixelPerCell;
+    g.cellMargin = (int)(p.perspectiveRemoveIgnoredMarginPerCell * p.perspectiveRemovePixelPerCell);
+    g.maxBorderErrors = (int)(c->markerSize * c->markerSize * p.maxErroneousBitsInBorderRate);
+    g.minOtsuStdDev = p.minOtsuStdDev;
+    g.maxCorrection = (int)((double)c->maxCorrectionBits * p.errorCorrectionRate);
+    g.minMarkerDistanceRate = (float)p.minMarkerDistanceRate;
+    g.minGroupDistance = p.minGroupDistance;
+    g.subpix = p.cornerRefinementMethod == 1;
+    g.subpixWin = p.cornerRefinementWinSize;
+    g.subpixMaxIter = p.cornerRefinementMaxIterations;
+    g.relWin = p.relativeCornerRefinmentWinSize;
+    g.subpixEps = p.cornerRefinementMinAccuracy;
+    g.dictN = c->dictN;
+    return g;
+}
+
+int check_params(camsync_ctx* c, const camsync_params* p) {
+    if (p->adaptiveThreshWinSizeMin < 3 || p->adaptiveThreshWinSizeMax < p->adaptiveThreshWinSizeMin ||
+        p->adaptiveThreshWinSizeStep <= 0)
+        return fail(c, CAMSYNC_E_ARG, "adaptive threshold window parameters out of range");
+    const int nScales = (p->adaptiveThreshWinSizeMax - p->adaptiveThreshWinSizeMin) / p->adaptiveThreshWinSizeStep + 1;
+    if (nScales > kMaxScales) return fail(c, CAMSYNC_E_ARG, "more than %d threshold scales", kMaxScales);
+    if (p->markerBorderBits < 1 || p->perspectiveRemovePixelPerCell < 1)
+        return fail(c, CAMSYNC_E_ARG, "markerBorderBits / perspectiveRemovePixelPerCell must be >= 1");
+    if ((c->markerSize + 2 * p->markerBorderBits) * p->perspectiveRemovePixelPerCell > 32 ||
+        (c->markerSize + 2 * p->markerBorderBits) * (c->markerSize + 2 * p->markerBorderBits) > 64)
+        return fail(c, CAMSYNC_E_ARG, "normalised marker image larger than 32x32 pixels / 64 cells");
+    if (p->cornerRefinementMethod != 0 && p->cornerRefinementMethod != 1)
+        return fail(c, CAMSYNC_E_ARG, "cornerRefinementMethod must be NONE(0) or SUBPIX(1)");
+    if (p->cornerRefinementMethod == 1 &&
+        (p->cornerRefinementWinSize < 1 || p->cornerRefinementWinSize > 20 || p->cornerRefinementMaxIterations < 1 ||
+         p->cornerRefinementMinAccuracy <= 0))
+        return fail(c, CAMSYNC_E_ARG, "corner refinement parameters out of range (winSize 1..20)");
+    return CAMSYNC_OK;
+}
+
+struct StageTimer {
+    camsync_ctx* c;
+    int idx = 0;
+    explicit StageTimer(camsync_ctx* c_) : c(c_) {
+        if (c->timing) (void)hipEventRecord(c->ev[0], c->stream);
+    }
+    void mark(int stage) {  // call after enqueuing `stage`
+        if (!c->timing) return;
+        (void)hipEventRecord(c->ev[stage + 1], c->stream);
+    }
+};
+
+// Enqueue the detection pipeline for one chunk already resident at d_in.
+int enqueue_detect(camsync_ctx* c, const uint8_t* d_in, int B, int H, int W, int C) {
+    DetCfg cfg = make_cfg(c, H, W);
+    DetBuffers b = c->buf;
+    b.in = d_in;
+    HIPCHK(c, hipMemsetAsync(b.counters, 0, sizeof(Counters), c->stream));
+    HIPCHK(c, hipMemsetAsync(b.qcount, 0, sizeof(int) * B, c->stream));
+    StageTimer t(c);
+    launch_gray_thresh(cfg, b, B, C, c->stream);
+    t.mark(0);
+    launch_contour_starts(cfg, b, B, c->stream);
+    t.mark(1);
+    launch_trace(cfg, b, c->stream);
+    t.mark(2);
+    launch_quad_fit(cfg, b, c->stream);
+    t.mark(3);
+    launch_identify(cfg, b, B, c->stream);
+    t.mark(4);
+    launch_select(cfg, b, B, c->stream);
+    t.mark(5);
+    launch_subpix(cfg, b, c->stream);
+    t.mark(6);
+    c->lastB = B;
+    c->lastH = H;
+    c->lastW = W;
+    HIPCHK(c, hipGetLastError());
+    return CAMSYNC_OK;
+}
+
+int collect_timers(camsync_ctx* c, int lastStage) {
+    if (!c->timing) return CAMSYNC_OK;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    float total = 0;
+    for (int s = 0; s <= lastStage; s++) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, c->ev[s], c->ev[s + 1]) == hipSuccess) {
+            c->ms[s] += ms;
+            c->launches[s]++;
+            total += ms;
+        }
+    }
+    c->ms[CAMSYNC_N_STAGES - 1] += total;
+    c->launches[CAMSYNC_N_STAGES - 1]++;
+    return CAMSYNC_OK;
+}
+
+int check_overflow(camsync_ctx* c) {
+    Counters h;
+    HIPCHK(c, hipMemcpyAsync(&h, c->buf.counters, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (h.overflow)
+        return fail(c, CAMSYNC_E_CAPACITY,
+                    "detection scratch overflow (mask 0x%x: 1 starts, 2 contours, 4 points, 8 quads, 32 markers); "
+                    "candidates %u contours %u points %u",
+                    h.overflow, h.nCand, h.nContours, h.nPool);
+    return CAMSYNC_OK;
+}
+
+int check_frame_args(camsync_ctx* c, const void* frames, int B, int H, int W, int C) {
+    if (!c) return CAMSYNC_E_ARG;
+    if (!frames || B <= 0) return fail(c, CAMSYNC_E_ARG, "frames is NULL or batch <= 0");
+    if (C != 1 && C != 3) return fail(c, CAMSYNC_E_ARG, "channels must be 1 or 3, got %d", C);
+    if (H > c->maxH || W > c->maxW || H < 32 || W < 32)
+        return fail(c, CAMSYNC_E_ARG, "frame %dx%d outside the context's range (32..%d x 32..%d)", H, W, c->maxH, c->maxW);
+    if (W % 8) return fail(c, CAMSYNC_E_ARG, "frame width must be a multiple of 8 (got %d)", W);
+    return CAMSYNC_OK;
+}
+
+int ensure_pose_scratch(camsync_ctx* c, size_t B, int N) {
+    if (B <= c->poseCap && N <= c->poseN) return CAMSYNC_OK;
+    const size_t nB = std::max(B, c->poseCap);
+    const int nN = std::max(N, c->poseN);
+    (void)hipFree(c->d_obj); (void)hipFree(c->d_img); (void)hipFree(c->d_npts); (void)hipFree(c->d_K); (void)hipFree(c->d_dist);
+    (void)hipFree(c->d_rvec); (void)hipFree(c->d_tvec); (void)hipFree(c->d_mae); (void)hipFree(c->d_rmse); (void)hipFree(c->d_ok);
+    c->d_obj = c->d_img = nullptr;
+    c->poseCap = 0;
+    HIPCHK(c, dalloc(&c->d_obj, nB * nN * 3));
+    HIPCHK(c, dalloc(&c->d_img, nB * nN * 2));
+    HIPCHK(c, dalloc(&c->d_npts, nB));
+    HIPCHK(c, dalloc(&c->d_K, nB * 9));
+    HIPCHK(c, dalloc(&c->d_dist, nB * 8));
+    HIPCHK(c, dalloc(&c->d_rvec, nB * 3));
+    HIPCHK(c, dalloc(&c->d_tvec, nB * 3));
+    HIPCHK(c, dalloc(&c->d_mae, nB));
+    HIPCHK(c, dalloc(&c->d_rmse, nB));
+    HIPCHK(c, dalloc(&c->d_ok, nB));
+    c->poseCap = nB;
+    c->poseN = nN;
+    return CAMSYNC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int camsync_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return CAMSYNC_E_NODEVICE;
+    return n;
+}
+
+void camsync_default_params(camsync_params* p) {
+    p->adaptiveThreshWinSizeMin = 3;
+    p->adaptiveThreshWinSizeMax = 23;
+    p->adaptiveThreshWinSizeStep = 10;
+    p->adaptiveThreshConstant = 7;
+    p->minMarkerPerimeterRate = 0.03;
+    p->maxMarkerPerimeterRate = 4.0;
+    p->polygonalApproxAccuracyRate = 0.03;
+    p->minCornerDistanceRate = 0.05;
+    p->minDistanceToBorder = 3;
+    p->markerBorderBits = 1;
+    p->minMarkerDistanceRate = 0.125;
+    p->minGroupDistance = 0.21f;
+    p->cornerRefinementMethod = 1;
+    p->cornerRefinementWinSize = 20;
+    p->relativeCornerRefinmentWinSize = 0.3f;
+    p->cornerRefinementMaxIterations = 100;
+    p->cornerRefinementMinAccuracy = 0.01;
+    p->perspectiveRemovePixelPerCell = 4;
+    p->perspectiveRemoveIgnoredMarginPerCell = 0.13;
+    p->maxErroneousBitsInBorderRate = 0.35;
+    p->minOtsuStdDev = 5.0;
+    p->errorCorrectionRate = 0.6;
+}
+
+int camsync_create(camsync_ctx** out, int device, int max_h, int max_w, int max_batch) {
+    if (!out || max_h < 32 || max_w < 32 || max_batch < 1) return CAMSYNC_E_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return CAMSYNC_E_NODEVICE;
+    camsync_ctx* c = new camsync_ctx();
+    *out = c;
+    c->device = device;
+    c->maxH = max_h;
+    c->maxW = max_w;
+    c->maxB = max_batch;
+    camsync_default_params(&c->params);
+    HIPCHK(c, hipSetDevice(device));
+    HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    const size_t px = (size_t)max_h * max_w, B = (size_t)max_batch;
+    DetBuffers& b = c->buf;
+    c->inBytes = B * px * 3;
+    HIPCHK(c, dalloc(&c->d_in, c->inBytes));
+    HIPCHK(c, dalloc(&b.gray, B * px));
+    HIPCHK(c, dalloc(&b.bin, B * px));
+    b.candCap = (unsigned)std::min<size_t>(B * (px / 16), 0x7FFFFFFFu);
+    HIPCHK(c, dalloc(&b.cand, b.candCap));
+    b.contourCap = (unsigned)std::min<size_t>(B * 4096, 0x7FFFFFFFu);
+    HIPCHK(c, dalloc(&b.contours, b.contourCap));
+    b.poolCap = (unsigned)std::min<size_t>(B * (size_t)262144, 0x7FFFFFFFu);
+    HIPCHK(c, dalloc(&b.pool, b.poolCap));
+    HIPCHK(c, dalloc(&b.quads, B * kQuadCap));
+    HIPCHK(c, dalloc(&b.qcount, B));
+    HIPCHK(c, dalloc(&b.counters, 1));
+    b.markerCap = (unsigned)(B * kMaxMarkerOut);
+    HIPCHK(c, dalloc(&b.markers, b.markerCap));
+    HIPCHK(c, dalloc(&b.outIds, B * kMaxMarkerOut));
+    HIPCHK(c, dalloc(&b.outCorners, B * kMaxMarkerOut * 8));
+    HIPCHK(c, dalloc(&b.rawCorners, B * kMaxMarkerOut * 8));
+    HIPCHK(c, dalloc(&b.outCounts, B));
+    HIPCHK(c, dalloc(&b.outRejected, B * kMaxRejectedOut * 8));
+    HIPCHK(c, dalloc(&b.outRejCounts, B));
+    HIPCHK(c, dalloc(&c->d_dict, 1024));
+    HIPCHK(c, dalloc(&c->d_expTab, 21 * 41));
+    HIPCHK(c, dalloc(&c->d_anchorIds, kMaxAnchors));
+    HIPCHK(c, dalloc(&c->d_anchorObj, kMaxAnchors * 12));
+    b.dict = c->d_dict;
+    b.expTab = c->d_expTab;
+    // cornerSubPix separable weights exp(-((i-win)/win)^2), float arithmetic as in OpenCV
+    std::vector<float> tab(21 * 41, 0.f);
+    for (int win = 1; win <= 20; win++)
+        for (int i = 0; i <= 2 * win; i++) {
+            float y = (float)(i - win) / win;
+            tab[win * 41 + i] = expf(-y * y);
+        }
+    HIPCHK(c, hipMemcpy(c->d_expTab, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
+    for (int i = 0; i <= CAMSYNC_N_STAGES; i++) HIPCHK(c, hipEventCreate(&c->ev[i]));
+    return CAMSYNC_OK;
+}
+
+void camsync_destroy(camsync_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    DetBuffers& b = c->buf;
+    void* ptrs[] = {c->d_in, b.gray, b.bin, b.cand, b.contours, b.pool, b.quads, b.qcount, b.counters, b.markers,
+                    b.outIds, b.outCorners, b.rawCorners, b.outCounts, b.outRejected, b.outRejCounts, c->d_dict, c->d_expTab,
+                    c->d_obj, c->d_img, c->d_npts, c->d_K, c->d_dist, c->d_rvec, c->d_tvec, c->d_mae, c->d_rmse, c->d_ok,
+                    c->d_anchorIds, c->d_anchorObj, c->d_calObj, c->d_calImg, c->cal.intr, c->cal.ext, c->cal.intrTrial,
+                    c->cal.extTrial, c->cal.viewBlocks, c->cal.partial, c->cal.acc, c->cal.errPartial, c->cal.errOut,
+                    c->d_calDelta, c->d_focalRows, c->d_focalAcc, c->d_calOk, c->d_calK, c->d_calNpts};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    for (int i = 0; i <= CAMSYNC_N_STAGES; i++)
+        if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* camsync_last_error(const camsync_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int camsync_set_params(camsync_ctx* c, const camsync_params* p) {
+    if (!c || !p) return CAMSYNC_E_ARG;
+    int rc = check_params(c, p);
+    if (rc) return rc;
+    c->params = *p;
+    return CAMSYNC_OK;
+}
+
+int camsync_get_params(const camsync_ctx* c, camsync_params* p) {
+    if (!c || !p) return CAMSYNC_E_ARG;
+    *p = c->params;
+    return CAMSYNC_OK;
+}
+
+int camsync_set_dictionary(camsync_ctx* c, const uint16_t* codes, int n, int marker_size, int max_correction_bits) {
+    if (!c) return CAMSYNC_E_ARG;
+    if (!codes || n < 1 || n > 1024) return fail(c, CAMSYNC_E_ARG, "dictionary must hold 1..1024 codes");
+    if (marker_size < 1 || marker_size > 4) return fail(c, CAMSYNC_E_ARG, "marker_size must be 1..4 (16-bit codes)");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpy(c->d_dict, codes, sizeof(uint16_t) * n, hipMemcpyHostToDevice));
+    const int oldSize = c->markerSize;
+    c->markerSize = marker_size;
+    int rc = check_params(c, &c->params);
+    if (rc) { c->markerSize = oldSize; return rc; }
+    c->dictN = n;
+    c->maxCorrectionBits = max_correction_bits;
+    return CAMSYNC_OK;
+}
+
+int camsync_gray_threshold(camsync_ctx* c, const uint8_t* frames, int on_device, int B, int H, int W, int C,
+                           uint8_t* gray_out, uint8_t* bin_out) {
+    int rc = check_frame_args(c, frames, B, H, W, C);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t px = (size_t)H * W;
+    const hipMemcpyKind outKind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    for (int b0 = 0; b0 < B; b0 += c->maxB) {
+        const int nb = std::min(c->maxB, B - b0);
+        const uint8_t* src = frames + (size_t)b0 * px * C;
+        const uint8_t* d_in = src;
+        if (!on_device) {
+            HIPCHK(c, hipMemcpyAsync(c->d_in, src, (size_t)nb * px * C, hipMemcpyHostToDevice, c->stream));
+            d_in = c->d_in;
+        } else if (((uintptr_t)src) % 8) {
+            return fail(c, CAMSYNC_E_ARG, "device frames must be 8-byte aligned");
+        }
+        DetCfg cfg = make_cfg(c, H, W);
+        DetBuffers b = c->buf;
+        b.in = d_in;
+        StageTimer t(c);
+        launch_gray_thresh(cfg, b, nb, C, c->stream);
+        t.mark(0);
+        HIPCHK(c, hipGetLastError());
+        if (gray_out) HIPCHK(c, hipMemcpyAsync(gray_out + (size_t)b0 * px, b.gray, (size_t)nb * px, outKind, c->stream));
+        if (bin_out) HIPCHK(c, hipMemcpyAsync(bin_out + (size_t)b0 * px, b.bin, (size_t)nb * px, outKind, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        rc = collect_timers(c, 0);
+        if (rc) return rc;
+    }
+    return CAMSYNC_OK;
+}
+
+static int detect_impl(camsync_ctx* c, const uint8_t* frames, int on_device, int B, int H, int W, int C,
+                       int max_markers, int32_t* ids, float* corners, int32_t* counts, int max_rejected, float* rejected,
+                       int32_t* rej_counts, const int32_t* anchor_ids, const float* anchor_obj, int n_anchor,
+                       const double* K, const double* dist, int ndist, int per_frame_cam, double* rvec, double* tvec,
+                       uint8_t* pose_ok, double* mae, double* rmse, bool withPose) {
+    int rc = check_frame_args(c, frames, B, H, W, C);
+    if (rc) return rc;
+    if (c->dictN <= 0) return fail(c, CAMSYNC_E_ARG, "no dictionary set (camsync_set_dictionary)");
+    if (max_markers < 1 || !ids || !corners || !counts) return fail(c, CAMSYNC_E_ARG, "detection outputs missing");
+    if (withPose) {
+        if (n_anchor < 1 || n_anchor > 16 || !anchor_ids || !anchor_obj)
+            return fail(c, CAMSYNC_E_ARG, "1..16 anchors required (one wavefront lane per anchor corner)");
+        if (!K || ndist < 0 || ndist > 8 || (ndist > 0 && !dist)) return fail(c, CAMSYNC_E_ARG, "camera matrix / distortion missing");
+        if (!rvec || !tvec || !pose_ok) return fail(c, CAMSYNC_E_ARG, "pose outputs missing");
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t px = (size_t)H * W;
+    std::vector<int32_t> hIds((size_t)c->maxB * kMaxMarkerOut), hCounts(c->maxB), hRejCounts(c->maxB);
+    std::vector<float> hCorners((size_t)c->maxB * kMaxMarkerOut * 8), hRej;
+    if (rejected) hRej.resize((size_t)c->maxB * kMaxRejectedOut * 8);
+    if (withPose) {
+        rc = ensure_pose_scratch(c, (size_t)c->maxB, 64);
+        if (rc) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->d_anchorIds, anchor_ids, sizeof(int32_t) * n_anchor, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->d_anchorObj, anchor_obj, sizeof(float) * n_anchor * 12, hipMemcpyHostToDevice, c->stream));
+    }
+    for (int b0 = 0; b0 < B; b0 += c->maxB) {
+        const int nb = std::min(c->maxB, B - b0);
+        const uint8_t* src = frames + (size_t)b0 * px * C;
+        const uint8_t* d_in = src;
+        if (!on_device) {
+            HIPCHK(c, hipMemcpyAsync(c->d_in, src, (size_t)nb * px * C, hipMemcpyHostToDevice, c->stream));
+            d_in = c->d_in;
+        } else if (((uintptr_t)src) % 8) {
+            return fail(c, CAMSYNC_E_ARG, "device frames must be 8-byte aligned");
+        }
+        rc = enqueue_detect(c, d_in, nb, H, W, C);
+        if (rc) return rc;
+        int lastStage = 6;
+        if (withPose) {
+            const size_t kOff = per_frame_cam ? (size_t)b0 : 0, kCnt = per_frame_cam ? (size_t)nb : 1;
+            HIPCHK(c, hipMemcpyAsync(c->d_K, K + kOff * 9, sizeof(double) * 9 * kCnt, hipMemcpyHostToDevice, c->stream));
+            if (ndist) HIPCHK(c, hipMemcpyAsync(c->d_dist, dist + kOff * ndist, sizeof(double) * ndist * kCnt, hipMemcpyHostToDevice, c->stream));
+            launch_gather_anchors(c->buf.outIds, c->buf.outCorners, c->buf.outCounts, nb, c->d_anchorIds, c->d_anchorObj,
+                                  n_anchor, c->d_obj, c->d_img, c->d_npts, c->stream);
+            PnpArgs a{};
+            a.obj = c->d_obj; a.img = c->d_img; a.npts = c->d_npts; a.B = nb; a.N = 64;
+            a.K = c->d_K; a.dist = c->d_dist; a.ndist = ndist; a.perFrameCam = per_frame_cam; a.refine = 1;
+            a.rvec = c->d_rvec; a.tvec = c->d_tvec; a.ok = c->d_ok; a.mae = c->d_mae; a.rmse = c->d_rmse;
+            launch_pnp(a, c->stream);
+            if (c->timing) (void)hipEventRecord(c->ev[8], c->stream);
+            lastStage = 7;
+            HIPCHK(c, hipMemcpyAsync(rvec + (size_t)b0 * 3, c->d_rvec, sizeof(double) * 3 * nb, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(tvec + (size_t)b0 * 3, c->d_tvec, sizeof(double) * 3 * nb, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(pose_ok + b0, c->d_ok, nb, hipMemcpyDeviceToHost, c->stream));
+            if (mae) HIPCHK(c, hipMemcpyAsync(mae + b0, c->d_mae, sizeof(double) * nb, hipMemcpyDeviceToHost, c->stream));
+            if (rmse) HIPCHK(c, hipMemcpyAsync(rmse + b0, c->d_rmse, sizeof(double) * nb, hipMemcpyDeviceToHost, c->stream));
+        }
+        HIPCHK(c, hipMemcpyAsync(hIds.data(), c->buf.outIds, sizeof(int32_t) * nb * kMaxMarkerOut, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(hCorners.data(), c->buf.outCorners, sizeof(float) * nb * kMaxMarkerOut * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(hCounts.data(), c->buf.outCounts, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, c->stream));
+        if (rejected) {
+            HIPCHK(c, hipMemcpyAsync(hRej.data(), c->buf.outRejected, sizeof(float) * nb * kMaxRejectedOut * 8, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(hRejCounts.data(), c->buf.outRejCounts, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, c->stream));
+        }
+        rc = check_overflow(c);  // synchronises the stream
+        if (rc) return rc;
+        rc = collect_timers(c, lastStage);
+        if (rc) return rc;
+        for (int f = 0; f < nb; f++) {
+            const int n = std::min(hCounts[f], max_markers);
+            counts[b0 + f] = n;
+            for (int m = 0; m < n; m++) {
+                ids[(size_t)(b0 + f) * max_markers + m] = hIds[(size_t)f * kMaxMarkerOut + m];
+                memcpy(corners + ((size_t)(b0 + f) * max_markers + m) * 8, &hCorners[((size_t)f * kMaxMarkerOut + m) * 8], 8 * sizeof(float));
+            }
+            if (rejected && rej_counts) {
+                const int nr = std::min(hRejCounts[f], max_rejected);
+                rej_counts[b0 + f] = nr;
+                for (int m = 0; m < nr; m++)
+                    memcpy(rejected + ((size_t)(b0 + f) * max_rejected + m) * 8, &hRej[((size_t)f * kMaxRejectedOut + m) * 8], 8 * sizeof(float));
+            }
+        }
+    }
+    return CAMSYNC_OK;
+}
+
+int camsync_detect_batch(camsync_ctx* c, const uint8_t* frames, int on_device, int B, int H, int W, int C,
+                         int max_markers, int32_t* ids, float* corners, int32_t* counts, int max_rejected,
+                         float* rejected, int32_t* rej_counts) {
+    return detect_impl(c, frames, on_device, B, H, W, C, max_markers, ids, corners, counts, max_rejected, rejected,
+                       rej_counts, nullptr, nullptr, 0, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, false);
+}
+
+int camsync_detect_pnp_batch(camsync_ctx* c, const uint8_t* frames, int on_device, int B, int H, int W, int C,
+                             const int32_t* anchor_ids, const float* anchor_obj, int n_anchor, const double* K,
+                             const double* dist, int ndist, int per_frame_cam, int max_markers, int32_t* ids,
+                             float* corners, int32_t* counts, double* rvec, double* tvec, uint8_t* pose_ok, double* mae,
+                             double* rmse) {
+    return detect_impl(c, frames, on_device, B, H, W, C, max_markers, ids, corners, counts, 0, nullptr, nullptr,
+                       anchor_ids, anchor_obj, n_anchor, K, dist, ndist, per_frame_cam, rvec, tvec, pose_ok, mae, rmse, true);
+}
+
+int camsync_detect_pnp_resident(camsync_ctx* c, const uint8_t* d_frames, int B, int H, int W, int C,
+                                const int32_t* anchor_ids, const float* anchor_obj, int n_anchor, const double* K,
+                                const double* dist, int ndist, int max_markers, int32_t* d_ids, float* d_corners,
+                                int32_t* d_counts, double* d_rvec, double* d_tvec, uint8_t* d_pose_ok) {
+    int rc = check_frame_args(c, d_frames, B, H, W, C);
+    if (rc) return rc;
+    if (c->dictN <= 0) return fail(c, CAMSYNC_E_ARG, "no dictionary set (camsync_set_dictionary)");
+    if (n_anchor < 1 || n_anchor > 16 || !anchor_ids || !anchor_obj) return fail(c, CAMSYNC_E_ARG, "1..16 anchors required");
+    if (!K || ndist < 0 || ndist > 8 || (ndist > 0 && !dist)) return fail(c, CAMSYNC_E_ARG, "camera matrix / distortion missing");
+    if (max_markers < 1 || !d_ids || !d_corners || !d_counts || !d_rvec || !d_tvec || !d_pose_ok)
+        return fail(c, CAMSYNC_E_ARG, "output pointers missing");
+    if (((uintptr_t)d_frames) % 8) return fail(c, CAMSYNC_E_ARG, "device frames must be 8-byte aligned");
+    HIPCHK(c, hipSetDevice(c->device));
+    rc = ensure_pose_scratch(c, (size_t)c->maxB, 64);
+    if (rc) return rc;
+    // anchors and camera are host pointers (small); frames and outputs live on the GPU
+    HIPCHK(c, hipMemcpyAsync(c->d_anchorIds, anchor_ids, sizeof(int32_t) * n_anchor, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_anchorObj, anchor_obj, sizeof(float) * n_anchor * 12, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_K, K, sizeof(double) * 9, hipMemcpyHostToDevice, c->stream));
+    if (ndist) HIPCHK(c, hipMemcpyAsync(c->d_dist, dist, sizeof(double) * ndist, hipMemcpyHostToDevice, c->stream));
+    const size_t px = (size_t)H * W;
+    const int mm = std::min(max_markers, kMaxMarkerOut);
+    unsigned int overflowSeen = 0;
+    for (int b0 = 0; b0 < B; b0 += c->maxB) {
+        const int nb = std::min(c->maxB, B - b0);
+        rc = enqueue_detect(c, d_frames + (size_t)b0 * px * C, nb, H, W, C);
+        if (rc) return rc;
+        launch_gather_anchors(c->buf.outIds, c->buf.outCorners, c->buf.outCounts, nb, c->d_anchorIds, c->d_anchorObj,
+                              n_anchor, c->d_obj, c->d_img, c->d_npts, c->stream);
+        PnpArgs a{};
+        a.obj = c->d_obj; a.img = c->d_img; a.npts = c->d_npts; a.B = nb; a.N = 64;
+        a.K = c->d_K; a.dist = c->d_dist; a.ndist = ndist; a.perFrameCam = 0; a.refine = 1;
+        a.rvec = d_rvec + (size_t)b0 * 3; a.tvec = d_tvec + (size_t)b0 * 3; a.ok = d_pose_ok + b0; a.mae = nullptr; a.rmse = nullptr;
+        launch_pnp(a, c->stream);
+        if (c->timing) (void)hipEventRecord(c->ev[8], c->stream);
+        HIPCHK(c, hipMemcpy2DAsync(d_ids + (size_t)b0 * max_markers, sizeof(int32_t) * max_markers, c->buf.outIds,
+                                   sizeof(int32_t) * kMaxMarkerOut, sizeof(int32_t) * mm, nb, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipMemcpy2DAsync(d_corners + (size_t)b0 * max_markers * 8, sizeof(float) * 8 * max_markers, c->buf.outCorners,
+                                   sizeof(float) * 8 * kMaxMarkerOut, sizeof(float) * 8 * mm, nb, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(d_counts + b0, c->buf.outCounts, sizeof(int32_t) * nb, hipMemcpyDeviceToDevice, c->stream));
+        // the scratch lists are reused by the next chunk: the stream orders that; overflow is checked per chunk
+        Counters h;
+        HIPCHK(c, hipMemcpyAsync(&h, c->buf.counters, sizeof h, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        overflowSeen |= h.overflow;
+        rc = collect_timers(c, 7);
+        if (rc) return rc;
+    }
+    if (overflowSeen) return fail(c, CAMSYNC_E_CAPACITY, "detection scratch overflow (mask 0x%x)", overflowSeen);
+    return CAMSYNC_OK;
+}
+
+int camsync_debug_counts(camsync_ctx* c, int frame, int32_t out[8]) {
+    if (!c || !out) return CAMSYNC_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    Counters h;
+    HIPCHK(c, hipMemcpy(&h, c->buf.counters, sizeof h, hipMemcpyDeviceToHost));
+    int q = 0;
+    if (frame >= 0 && frame < c->lastB) HIPCHK(c, hipMemcpy(&q, c->buf.qcount + frame, sizeof q, hipMemcpyDeviceToHost));
+    out[0] = (int32_t)h.nCand; out[1] = (int32_t)h.nContours; out[2] = (int32_t)h.nPool; out[3] = (int32_t)h.nMarkers;
+    out[4] = (int32_t)h.overflow; out[5] = q; out[6] = c->lastB; out[7] = 0;
+    return CAMSYNC_OK;
+}
+
+int camsync_debug_quads(camsync_ctx* c, int frame, int max_quads, float* corners, int32_t* scale, int32_t* scan_key,
+                        int32_t* contour_len, int32_t* id, int32_t* rot) {
+    if (!c || frame < 0 || frame >= c->lastB) return CAMSYNC_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    int q = 0;
+    HIPCHK(c, hipMemcpy(&q, c->buf.qcount + frame, sizeof q, hipMemcpyDeviceToHost));
+    q = std::min(q, kQuadCap);
+    std::vector<QuadRec> h(q);
+    if (q) HIPCHK(c, hipMemcpy(h.data(), c->buf.quads + (size_t)frame * kQuadCap, sizeof(QuadRec) * q, hipMemcpyDeviceToHost));
+    for (int i = 0; i < q && i < max_quads; i++) {
+        for (int k = 0; k < 8; k++) corners[i * 8 + k] = (float)h[i].c[k];
+        if (scale) scale[i] = h[i].scale;
+        if (scan_key) scan_key[i] = (int32_t)h[i].scanKey;
+        if (contour_len) contour_len[i] = h[i].clen;
+        if (id) id[i] = h[i].valid ? h[i].id : -1;
+        if (rot) rot[i] = h[i].rot;
+    }
+    return q;
+}
+
+int camsync_debug_contours(camsync_ctx* c, int frame, int max_contours, int32_t* scale, int32_t* start_key,
+                           int32_t* is_hole, int32_t* length) {
+    if (!c || frame < 0 || frame >= c->lastB) return CAMSYNC_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    Counters hc;
+    HIPCHK(c, hipMemcpy(&hc, c->buf.counters, sizeof hc, hipMemcpyDeviceToHost));
+    const unsigned n = std::min(hc.nContours, c->buf.contourCap);
+    std::vector<ContourRec> h(n);
+    if (n) HIPCHK(c, hipMemcpy(h.data(), c->buf.contours, sizeof(ContourRec) * n, hipMemcpyDeviceToHost));
+    int k = 0;
+    for (unsigned i = 0; i < n; i++) {
+        if ((int)h[i].frame != frame) continue;
+        if (k < max_contours) {
+            if (scale) scale[k] = h[i].scale;
+            if (start_key) start_key[k] = (int32_t)h[i].pos;
+            if (is_hole) is_hole[k] = h[i].hole;
+            if (length) length[k] = (int32_t)h[i].len;
+        }
+        k++;
+    }
+    return k;
+}
+
+int camsync_pnp_batch(camsync_ctx* c, const float* obj, const float* img, const int32_t* npts, int B, int N,
+                      const double* K, const double* dist, int ndist, int per_frame_cam, double* rvec, double* tvec,
+                      uint8_t* ok, double* mae, double* rmse) {
+    if (!c) return CAMSYNC_E_ARG;
+    if (!obj || !img || !npts || !K || !rvec || !tvec || !ok || B <= 0) return fail(c, CAMSYNC_E_ARG, "missing argument");
+    if (N < 4 || N > 64) return fail(c, CAMSYNC_E_ARG, "N must be 4..64 points per frame (one wavefront lane per point)");
+    if (ndist < 0 || ndist > 8 || (ndist > 0 && !dist)) return fail(c, CAMSYNC_E_ARG, "ndist must be 0..8");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = ensure_pose_scratch(c, (size_t)B, N);
+    if (rc) return rc;
+    const size_t kc = per_frame_cam ? (size_t)B : 1;
+    HIPCHK(c, hipMemcpyAsync(c->d_obj, obj, sizeof(float) * 3 * N * B, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_img, img, sizeof(float) * 2 * N * B, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_npts, npts, sizeof(int32_t) * B, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_K, K, sizeof(double) * 9 * kc, hipMemcpyHostToDevice, c->stream));
+    if (ndist) HIPCHK(c, hipMemcpyAsync(c->d_dist, dist, sizeof(double) * ndist * kc, hipMemcpyHostToDevice, c->stream));
+    PnpArgs a{};
+    a.obj = c->d_obj; a.img = c->d_img; a.npts = c->d_npts; a.B = B; a.N = N;
+    a.K = c->d_K; a.dist = c->d_dist; a.ndist = ndist; a.perFrameCam = per_frame_cam; a.refine = 1;
+    a.rvec = c->d_rvec; a.tvec = c->d_tvec; a.ok = c->d_ok; a.mae = c->d_mae; a.rmse = c->d_rmse;
+    if (c->timing) (void)hipEventRecord(c->ev[7], c->stream);
+    launch_pnp(a, c->stream);
+    if (c->timing) (void)hipEventRecord(c->ev[8], c->stream);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(rvec, c->d_rvec, sizeof(double) * 3 * B, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(tvec, c->d_tvec, sizeof(double) * 3 * B, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(ok, c->d_ok, B, hipMemcpyDeviceToHost, c->stream));
+    if (mae) HIPCHK(c, hipMemcpyAsync(mae, c->d_mae, sizeof(double) * B, hipMemcpyDeviceToHost, c->stream));
+    if (rmse) HIPCHK(c, hipMemcpyAsync(rmse, c->d_rmse, sizeof(double) * B, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->timing) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, c->ev[7], c->ev[8]) == hipSuccess) { c->ms[7] += ms; c->launches[7]++; }
+    }
+    return CAMSYNC_OK;
+}
+
+int camsync_ippe_square_batch(camsync_ctx* c, const float* corners, const double* size, int B, const double* K,
+                              const double* dist, int ndist, int per_frame_cam, double* rvec, double* tvec, uint8_t* ok) {
+    if (!c) return CAMSYNC_E_ARG;
+    if (!corners || !size || !K || !rvec || !tvec || B <= 0) return fail(c, CAMSYNC_E_ARG, "missing argument");
+    if (ndist < 0 || ndist > 8 || (ndist > 0 && !dist)) return fail(c, CAMSYNC_E_ARG, "ndist must be 0..8");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = ensure_pose_scratch(c, (size_t)B, 4);
+    if (rc) return rc;
+    const size_t kc = per_frame_cam ? (size_t)B : 1;
+    // reuse the pose scratch: corners -> d_img (B*4*2 floats), sizes -> d_mae
+    HIPCHK(c, hipMemcpyAsync(c->d_img, corners, sizeof(float) * 8 * B, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_mae, size, sizeof(double) * B, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_K, K, sizeof(double) * 9 * kc, hipMemcpyHostToDevice, c->stream));
+    if (ndist) HIPCHK(c, hipMemcpyAsync(c->d_dist, dist, sizeof(double) * ndist * kc, hipMemcpyHostToDevice, c->stream));
+    launch_ippe(c->d_img, c->d_mae, B, c->d_K, c->d_dist, ndist, per_frame_cam, c->d_rvec, c->d_tvec, c->d_ok, c->stream);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(rvec, c->d_rvec, sizeof(double) * 3 * B, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(tvec, c->d_tvec, sizeof(double) * 3 * B, hipMemcpyDeviceToHost, c->stream));
+    if (ok) HIPCHK(c, hipMemcpyAsync(ok, c->d_ok, B, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return CAMSYNC_OK;
+}
+
+/* ---- calibration ---- */
+
+int camsync_calib_begin(camsync_ctx* c, const float* obj, const float* img, int V, int P, int flags) {
+    if (!c) return CAMSYNC_E_ARG;
+    if (V < 0 || P < 4 || P > 64 || (V > 0 && (!obj || !img)))
+        return fail(c, CAMSYNC_E_ARG, "calibration needs 4..64 points per view (one wavefront lane per point)");
+    HIPCHK(c, hipSetDevice(c->device));
+    CalibState& s = c->cal;
+    void* old[] = {c->d_calObj, c->d_calImg, s.intr, s.ext, s.intrTrial, s.extTrial, s.viewBlocks, s.partial, s.acc,
+                   s.errPartial, s.errOut, c->d_calDelta, c->d_focalRows, c->d_focalAcc, c->d_calOk, c->d_calK, c->d_calNpts};
+    for (void* p : old)
+        if (p) (void)hipFree(p);
+    c->calReady = false;
+    s = CalibState{};
+    s.V = V;
+    s.P = P;
+    s.NI = (flags & 1) ? 12 : 9;
+    const int L = s.NI * s.NI + s.NI + 1;
+    const size_t nv = (size_t)std::max(V, 1);
+    HIPCHK(c, dalloc(&c->d_calObj, nv * P * 3));
+    HIPCHK(c, dalloc(&c->d_calImg, nv * P * 2));
+    HIPCHK(c, dalloc(&s.intr, 12));
+    HIPCHK(c, dalloc(&s.ext, nv * 6));
+    HIPCHK(c, dalloc(&s.intrTrial, 12));
+    HIPCHK(c, dalloc(&s.extTrial, nv * 6));
+    HIPCHK(c, dalloc(&s.viewBlocks, nv * (6 * s.NI + 6)));
+    HIPCHK(c, dalloc(&s.partial, nv * L));
+    HIPCHK(c, dalloc(&s.acc, (size_t)L));
+    HIPCHK(c, dalloc(&s.errPartial, nv));
+    HIPCHK(c, dalloc(&s.errOut, 1));
+    HIPCHK(c, dalloc(&c->d_calDelta, 12));
+    HIPCHK(c, dalloc(&c->d_focalRows, nv * 6));
+    HIPCHK(c, dalloc(&c->d_focalAcc, 6));
+    HIPCHK(c, dalloc(&c->d_calOk, nv));
+    HIPCHK(c, dalloc(&c->d_calK, 9 + 8));
+    HIPCHK(c, dalloc(&c->d_calNpts, nv));
+    if (V > 0) {
+        HIPCHK(c, hipMemcpy(c->d_calObj, obj, sizeof(float) * (size_t)V * P * 3, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(c->d_calImg, img, sizeof(float) * (size_t)V * P * 2, hipMemcpyHostToDevice));
+        std::vector<int32_t> np(V, P);
+        HIPCHK(c, hipMemcpy(c->d_calNpts, np.data(), sizeof(int32_t) * V, hipMemcpyHostToDevice));
+    }
+    HIPCHK(c, hipMemset(s.intr, 0, sizeof(double) * 12));
+    HIPCHK(c, hipMemset(s.ext, 0, sizeof(double) * nv * 6));
+    s.obj = c->d_calObj;
+    s.img = c->d_calImg;
+    c->calReady = true;
+    return CAMSYNC_OK;
+}
+
+int camsync_calib_n_intrinsics(const camsync_ctx* c) { return (c && c->calReady) ? c->cal.NI : CAMSYNC_E_ARG; }
+
+int camsync_calib_focal_acc(camsync_ctx* c, int W, int H, double acc6[6]) {
+    if (!c || !c->calReady || !acc6) return CAMSYNC_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    for (int i = 0; i < 6; i++) acc6[i] = 0;
+    if (c->cal.V == 0) return CAMSYNC_OK;
+    const double cx = (!W) ? 0.5 : (W - 1) * 0.5, cy = (!H) ? 0.5 : (H - 1) * 0.5;
+    launch_calib_focal_rows(c->cal, cx, cy, c->d_focalRows, c->d_focalAcc, c->stream);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(acc6, c->d_focalAcc, sizeof(double) * 6, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return CAMSYNC_OK;
+}
+
+int camsync_calib_set_intrinsics(camsync_ctx* c, const double intr[12], int init_extrinsics) {
+    if (!c || !c->calReady || !intr) return CAMSYNC_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    CalibState& s = c->cal;
+    HIPCHK(c, hipMemcpyAsync(s.intr, intr, sizeof(double) * 12, hipMemcpyHostToDevice, c->stream));
+    if (init_extrinsics && s.V > 0) {
+        // cvFindExtrinsicCameraParams2 per view with the initial camera matrix and zero distortion
+        double Kd[17] = {intr[0], 0, intr[2], 0, intr[1], intr[3], 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0};
+        HIPCHK(c, hipMemcpyAsync(c->d_calK, Kd, sizeof Kd, hipMemcpyHostToDevice, c->stream));
+        int rc = ensure_pose_scratch(c, (size_t)s.V, 4);
+        if (rc) return rc;
+        PnpArgs a{};
+        a.obj = s.obj; a.img = s.img; a.npts = c->d_calNpts; a.B = s.V; a.N = s.P;
+        a.K = c->d_calK; a.dist = c->d_calK + 9; a.ndist = 0; a.perFrameCam = 0; a.refine = 0;
+        a.rvec = c->d_rvec; a.tvec = c->d_tvec; a.ok = c->d_calOk; a.mae = nullptr; a.rmse = nullptr;
+        launch_pnp(a, c->stream);
+        HIPCHK(c, hipGetLastError());
+        // interleave rvec/tvec into ext [V,6]
+        HIPCHK(c, hipMemcpy2DAsync(s.ext, sizeof(double) * 6, c->d_rvec, sizeof(double) * 3, sizeof(double) * 3, s.V, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipMemcpy2DAsync(s.ext + 3, sizeof(double) * 6, c->d_tvec, sizeof(double) * 3, sizeof(double) * 3, s.V, hipMemcpyDeviceToDevice, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return CAMSYNC_OK;
+}
+
+int camsync_calib_accumulate(camsync_ctx* c, double lambda, double* acc, int acc_on_device) {
+    if (!c || !c->calReady || !acc) return CAMSYNC_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    CalibState& s = c->cal;
+    const int L = s.NI * s.NI + s.NI + 1;
+    if (s.V > 0) {
+        launch_calib_accumulate(s, lambda, c->stream);
+        HIPCHK(c, hipGetLastError());
+    } else {
+        HIPCHK(c, hipMemsetAsync(s.acc, 0, sizeof(double) * L, c->stream));
+    }
+    HIPCHK(c, hipMemcpyAsync(acc, s.acc, sizeof(double) * L, acc_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return CAMSYNC_OK;
+}
+
+int camsync_calib_solve(const double* acc, int ni, double* delta) {
+    if (!acc || !delta || ni < 1 || ni > 12) return CAMSYNC_E_ARG;
+    // symmetric positive definite ni x ni system S d = r; Cholesky, falling back to a ridge when a pivot vanishes
+    double A[144], b[12];
+    for (int attempt = 0; attempt < 2; attempt++) {
+        double tr = 0;
+        for (int i = 0; i < ni; i++) tr += acc[i * ni + i];
+        for (int i = 0; i < ni * ni; i++) A[i] = acc[i];
+        if (attempt)
+            for (int i = 0; i < ni; i++) A[i * ni + i] += 1e-14 * tr + 1e-300;
+        for (int i = 0; i < ni; i++) b[i] = acc[ni * ni + i];
+        bool ok = true;
+        for (int j = 0; j < ni && ok; j++) {
+            double s = A[j * ni + j];
+            for (int k = 0; k < j; k++) s -= A[j * ni + k] * A[j * ni + k];
+            if (!(s > 0)) { ok = false; break; }
+            const double d = sqrt(s);
+            A[j * ni + j] = d;
+            for (int i = j + 1; i < ni; i++) {
+                double t = A[i * ni + j];
+                for (int k = 0; k < j; k++) t -= A[i * ni + k] * A[j * ni + k];
+                A[i * ni + j] = t / d;
+            }
+        }
+        if (!ok) continue;
+        for (int i = 0; i < ni; i++) {
+            double s = b[i];
+            for (int k = 0; k < i; k++) s -= A[i * ni + k] * b[k];
+            b[i] = s / A[i * ni + i];
+        }
+        for (int i = ni - 1; i >= 0; i--) {
+            double s = b[i];
+            for (int k = i + 1; k < ni; k++) s -= A[k * ni + i] * b[k];
+            b[i] = s / A[i * ni + i];
+        }
+        for (int i = 0; i < ni; i++) delta[i] = b[i];
+        return CAMSYNC_OK;
+    }
+    return CAMSYNC_E_NUMERIC;
+}
+
+int camsync_calib_step(camsync_ctx* c, const double* delta, double* err_out) {
+    if (!c || !c->calReady || !delta || !err_out) return CAMSYNC_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    CalibState& s = c->cal;
+    HIPCHK(c, hipMemcpyAsync(c->d_calDelta, delta, sizeof(double) * s.NI, hipMemcpyHostToDevice, c->stream));
+    launch_calib_backsub(s, c->d_calDelta, c->stream);
+    *err_out = 0;
+    if (s.V > 0) {
+        launch_calib_error(s, 1, c->stream);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(err_out, s.errOut, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return CAMSYNC_OK;
+}
+
+int camsync_calib_accept(camsync_ctx* c) {
+    if (!c || !c->calReady) return CAMSYNC_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    launch_calib_accept(c->cal, c->stream);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return CAMSYNC_OK;
+}
+
+int camsync_calib_get(camsync_ctx* c, double intr[12], double* rvecs, double* tvecs) {
+    if (!c || !c->calReady) return CAMSYNC_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    CalibState& s = c->cal;
+    if (intr) HIPCHK(c, hipMemcpy(intr, s.intr, sizeof(double) * 12, hipMemcpyDeviceToHost));
+    if ((rvecs || tvecs) && s.V > 0) {
+        std::vector<double> e((size_t)s.V * 6);
+        HIPCHK(c, hipMemcpy(e.data(), s.ext, sizeof(double) * e.size(), hipMemcpyDeviceToHost));
+        for (int v = 0; v < s.V; v++)
+            for (int q = 0; q < 3; q++) {
+                if (rvecs) rvecs[3 * v + q] = e[(size_t)v * 6 + q];
+                if (tvecs) tvecs[3 * v + q] = e[(size_t)v * 6 + 3 + q];
+            }
+    }
+    return CAMSYNC_OK;
+}
+
+// Single-GPU driver: cvCalibrateCamera2Internal's flow (focal init, per-view
+// extrinsic init, CvLevMarq::updateAlt loop with criteria (COUNT+EPS, max_iter,
+// DBL_EPSILON)).
+int camsync_calibrate(camsync_ctx* c, const float* obj, const float* img, int V, int P, int W, int H, int flags,
+                      int max_iter, double* K, double* dist, double* rvecs, double* tvecs, double* rms, int32_t* iters) {
+    if (!c) return CAMSYNC_E_ARG;
+    if (V < 1 || !K || !dist) return fail(c, CAMSYNC_E_ARG, "need at least one view and K/dist outputs");
+    if (max_iter <= 0) max_iter = 30;
+    int rc = camsync_calib_begin(c, obj, img, V, P, flags);
+    if (rc) return rc;
+    const int NI = c->cal.NI, L = NI * NI + NI + 1;
+    double f6[6];
+    rc = camsync_calib_focal_acc(c, W, H, f6);
+    if (rc) return rc;
+    // 2x2 normal equations for (1/fx^2, 1/fy^2)
+    const double det = f6[0] * f6[2] - f6[1] * f6[1];
+    if (!(fabs(det) > 0)) return fail(c, CAMSYNC_E_NUMERIC, "focal length initialisation is singular");
+    const double f0 = (f6[3] * f6[2] - f6[4] * f6[1]) / det, f1 = (f6[0] * f6[4] - f6[1] * f6[3]) / det;
+    double intr[12] = {sqrt(fabs(1. / f0)), sqrt(fabs(1. / f1)), (!W) ? 0.5 : (W - 1) * 0.5, (!H) ? 0.5 : (H - 1) * 0.5,
+                       0, 0, 0, 0, 0, 0, 0, 0};
+    rc = camsync_calib_set_intrinsics(c, intr, 1);
+    if (rc) return rc;
+    std::vector<double> acc(L);
+    double delta[12];
+    int lambdaLg10 = -3, it = 0;
+    double prevErr = 0, errNorm = 0;
+    for (;;) {
+        double lambda = exp(lambdaLg10 * log(10.));
+        rc = camsync_calib_accumulate(c, lambda, acc.data(), 0);
+        if (rc) return rc;
+        if (it == 0) prevErr = acc[L - 1];
+        for (;;) {
+            rc = camsync_calib_solve(acc.data(), NI, delta);
+            if (rc) return fail(c, rc, "intrinsic block is singular");
+            rc = camsync_calib_step(c, delta, &errNorm);
+            if (rc) return rc;
+            if (errNorm > prevErr && ++lambdaLg10 <= 16) {
+                lambda = exp(lambdaLg10 * log(10.));
+                rc = camsync_calib_accumulate(c, lambda, acc.data(), 0);
+                if (rc) return rc;
+                continue;
+            }
+            break;
+        }
+        lambdaLg10 = std::max(lambdaLg10 - 1, -16);
+        // relative parameter change ||p - p_prev|| / ||p_prev||
+        std::vector<double> cur((size_t)V * 6 + 12), tri((size_t)V * 6 + 12);
+        HIPCHK(c, hipMemcpy(cur.data(), c->cal.intr, sizeof(double) * 12, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(cur.data() + 12, c->cal.ext, sizeof(double) * V * 6, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(tri.data(), c->cal.intrTrial, sizeof(double) * 12, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(tri.data() + 12, c->cal.extTrial, sizeof(double) * V * 6, hipMemcpyDeviceToHost));
+        double dn = 0, pn = 0;
+        for (size_t i = 0; i < cur.size(); i++) { dn += (tri[i] - cur[i]) * (tri[i] - cur[i]); pn += cur[i] * cur[i]; }
+        rc = camsync_calib_accept(c);
+        if (rc) return rc;
+        const double change = sqrt(dn) / sqrt(pn);
+        if (++it >= max_iter || change < 2.220446049250313e-16) break;
+        prevErr = errNorm;
+    }
+    double out[12];
+    rc = camsync_calib_get(c, out, rvecs, tvecs);
+    if (rc) return rc;
+    for (int i = 0; i < 9; i++) K[i] = 0;
+    K[0] = out[0]; K[4] = out[1]; K[2] = out[2]; K[5] = out[3]; K[8] = 1;
+    for (int i = 0; i < NI - 4; i++) dist[i] = out[4 + i];
+    if (rms) *rms = sqrt(errNorm / ((double)V * P));
+    if (iters) *iters = it;
+    return CAMSYNC_OK;
+}
+
+/* ---- timers ---- */
+
+int camsync_enable_timers(camsync_ctx* c, int on) {
+    if (!c) return CAMSYNC_E_ARG;
+    c->timing = on != 0;
+    return CAMSYNC_OK;
+}
+
+int camsync_get_timers(camsync_ctx* c, double ms[CAMSYNC_N_STAGES], int64_t launches[CAMSYNC_N_STAGES]) {
+    if (!c) return CAMSYNC_E_ARG;
+    for (int i = 0; i < CAMSYNC_N_STAGES; i++) {
+        if (ms) ms[i] = c->ms[i];
+        if (launches) launches[i] = c->launches[i];
+    }
+    return CAMSYNC_OK;
+}
+
+int camsync_reset_timers(camsync_ctx* c) {
+    if (!c) return CAMSYNC_E_ARG;
+    for (int i = 0; i < CAMSYNC_N_STAGES; i++) { c->ms[i] = 0; c->launches[i] = 0; }
+    return CAMSYNC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,158 @@
+// internal.h — shared declarations of libcamsync_hip (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/camsync.h"
+
+namespace camsync {
+
+constexpr int kMaxScales = 8;
+constexpr int kQuadCap = 256;      // quad candidates kept per frame
+constexpr int kSelCap = 256;       // selected candidates per frame
+constexpr int kMaxMarkerOut = 64;  // accepted markers per frame held on device
+constexpr int kMaxRejectedOut = kSelCap;
+constexpr int kMaxAnchors = 64;
+
+// Detection configuration, derived from camsync_params + frame size and passed
+// to kernels by value.
+struct DetCfg {
+    int H, W;
+    int nScales;
+    int radius[kMaxScales];  // adaptive threshold half windows
+    int idelta;              // floor(adaptiveThreshConstant)
+    int minPerim, maxPerim;  // contour length bounds (points)
+    double accuracyRate;     // polygonalApproxAccuracyRate
+    double minCornerDistanceRate;
+    int minDistToBorder;
+    int borderBits, markerSize, cellSize, cellMargin;
+    int maxBorderErrors;     // int(markerSize^2 * maxErroneousBitsInBorderRate)
+    double minOtsuStdDev;
+    int maxCorrection;       // int(maxCorrectionBits * errorCorrectionRate)
+    float minMarkerDistanceRate, minGroupDistance;
+    int subpix;              // cornerRefinementMethod == SUBPIX
+    int subpixWin, subpixMaxIter;
+    float relWin;
+    double subpixEps;
+    int dictN;
+};
+
+// 64-bit contour-start candidate: frame<<40 | hole<<39 | scale<<36 | pos(y*W+x)
+__host__ __device__ inline uint64_t pack_cand(uint32_t frame, uint32_t hole, uint32_t scale, uint32_t pos) {
+    return ((uint64_t)frame << 40) | ((uint64_t)hole << 39) | ((uint64_t)scale << 36) | (uint64_t)pos;
+}
+
+struct ContourRec {
+    uint32_t frame;
+    uint32_t pos;      // start pixel y*W+x
+    uint32_t len;      // number of points
+    uint32_t off;      // offset into the point pool
+    uint16_t scale;
+    uint16_t hole;
+    uint32_t scanKey;  // raster position at which the sequential scan discovers it
+};
+
+struct QuadRec {
+    int16_t c[8];      // corners after the clockwise reorder, x0,y0,..x3,y3
+    uint32_t scanKey;
+    uint16_t scale;
+    uint16_t valid;    // identification result
+    int32_t clen;      // contour length
+    int32_t id, rot;
+};
+
+struct MarkerRec {      // accepted marker, compact list for sub-pixel refinement
+    uint32_t frame;
+    uint32_t slot;      // index in the frame's output
+};
+
+struct Counters {
+    unsigned int nCand;
+    unsigned int nContours;
+    unsigned int nPool;
+    unsigned int nMarkers;
+    unsigned int overflow;  // bit0 cand, bit1 contours, bit2 pool, bit3 quads, bit4 sel, bit5 markers
+    unsigned int pad[3];
+};
+
+struct DetBuffers {
+    const uint8_t* in;   // [B,H,W,C]
+    uint8_t* gray;       // [B,H,W]
+    uint8_t* bin;        // [B,H,W] packed scale bits
+    uint64_t* cand;
+    unsigned int candCap;
+    ContourRec* contours;
+    unsigned int contourCap;
+    uint32_t* pool;
+    unsigned int poolCap;
+    QuadRec* quads;      // [B,kQuadCap]
+    int* qcount;         // [B]
+    Counters* counters;
+    MarkerRec* markers;  // compact accepted list
+    unsigned int markerCap;
+    // per-frame outputs
+    int32_t* outIds;     // [B,kMaxMarkerOut]
+    float* outCorners;   // [B,kMaxMarkerOut,8] final (sub-pixel) corners
+    float* rawCorners;   // [B,kMaxMarkerOut,8] integer corners before refinement
+    int32_t* outCounts;  // [B]
+    float* outRejected;  // [B,kMaxRejectedOut,8]
+    int32_t* outRejCounts;
+    // tables
+    const uint16_t* dict;   // dictN codes
+    const float* expTab;    // [21][41] separable cornerSubPix weights
+};
+
+// launchers (each enqueues on `st`, no sync)
+void launch_gray_thresh(const DetCfg& c, const DetBuffers& b, int B, int C, hipStream_t st);
+void launch_contour_starts(const DetCfg& c, const DetBuffers& b, int B, hipStream_t st);
+void launch_trace(const DetCfg& c, const DetBuffers& b, hipStream_t st);
+void launch_quad_fit(const DetCfg& c, const DetBuffers& b, hipStream_t st);
+void launch_identify(const DetCfg& c, const DetBuffers& b, int B, hipStream_t st);
+void launch_select(const DetCfg& c, const DetBuffers& b, int B, hipStream_t st);
+void launch_subpix(const DetCfg& c, const DetBuffers& b, hipStream_t st);
+
+// pose
+struct PnpArgs {
+    const float* obj;      // [B,N,3]
+    const float* img;      // [B,N,2]
+    const int32_t* npts;   // [B]
+    int B, N;
+    const double* K;       // [B or 1, 9]
+    const double* dist;    // [B or 1, ndist]
+    int ndist, perFrameCam;
+    int refine;            // run the solvePnPRefineLM phase
+    double* rvec;          // [B,3]
+    double* tvec;          // [B,3]
+    uint8_t* ok;           // [B]
+    double* mae;           // [B] or null
+    double* rmse;          // [B] or null
+};
+void launch_pnp(const PnpArgs& a, hipStream_t st);
+void launch_gather_anchors(const int32_t* ids, const float* corners, const int32_t* counts, int B,
+                           const int32_t* anchorIds, const float* anchorObj, int nAnchor,
+                           float* obj, float* img, int32_t* npts, hipStream_t st);
+void launch_ippe(const float* corners, const double* size, int B, const double* K, const double* dist,
+                 int ndist, int perFrameCam, double* rvec, double* tvec, uint8_t* ok, hipStream_t st);
+
+// calibration
+struct CalibState {
+    int V, P, NI;          // local views, points per view, active intrinsics (9 or 12)
+    const float* obj;      // [V,P,3]
+    const float* img;      // [V,P,2]
+    double* intr;          // [12] fx fy cx cy k1 k2 p1 p2 k3 k4 k5 k6 (current)
+    double* ext;           // [V,6] current
+    double* intrTrial;     // [12]
+    double* extTrial;      // [V,6]
+    double* viewBlocks;    // [V, 6*NI + 6] Aee'^-1 Bie^T and Aee'^-1 g_e saved by accumulate
+    double* partial;       // [V, NI*NI + NI + 1] per-view Schur records
+    double* acc;           // [NI*NI + NI + 1] reduced: S | rhs | err
+    double* errPartial;    // [V]
+    double* errOut;        // [1]
+};
+void launch_calib_accumulate(const CalibState& s, double lambda, hipStream_t st);
+void launch_calib_backsub(const CalibState& s, const double* di, hipStream_t st);
+void launch_calib_error(const CalibState& s, int useTrial, hipStream_t st);
+void launch_calib_focal_rows(const CalibState& s, double cx, double cy, double* rows, double* acc6, hipStream_t st);
+void launch_calib_accept(const CalibState& s, hipStream_t st);
+
+}  // namespace camsync

@@ -1,0 +1,228 @@
+// k_quads.hip — K4: the per-contour part of _findMarkerContours
+// (ArucoDetector.detectMarkers step 1c; reference camera_sync/aruco.py:256-264):
+// approxPolyDP(eps = 0.03 * n, closed), 4 vertices, convex, minimum side,
+// distance to the image border, clockwise reorder.
+//
+// One wavefront per contour.  The contour points sit in the pool as
+// x | y<<16.  Douglas–Peucker's farthest-point searches are wave-wide arg-max
+// reductions with OpenCV's tie rule (first maximum in traversal order); all
+// distances are integers, so the reductions are exact.  The recursion is
+// driven from a 16-entry LDS stack: a polygon that needs more than 8 vertices
+// before the clean-up pass can never end with 4, so it is dropped early.
+#include "internal.h"
+
+namespace camsync {
+
+namespace {
+
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        unsigned long long o = __shfl_xor(v, d, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+struct IPt { int x, y; };
+__device__ __forceinline__ IPt unpack_pt(uint32_t p) { return IPt{(int)(p & 0xFFFFu), (int)(p >> 16)}; }
+
+__global__ __launch_bounds__(64) void k_quad_fit(const ContourRec* __restrict__ contours, unsigned int contourCap,
+                                                 const uint32_t* __restrict__ pool, QuadRec* __restrict__ quads,
+                                                 int* __restrict__ qcount, Counters* __restrict__ ctr, DetCfg cfg) {
+    __shared__ int s_stack[32][2];
+    __shared__ IPt s_dst[16];
+    const int lane = threadIdx.x;
+    const unsigned int nC = min(ctr->nContours, contourCap);
+    for (unsigned int ci = blockIdx.x; ci < nC; ci += gridDim.x) {
+        __syncthreads();
+        const ContourRec rec = contours[ci];
+        const int n = (int)rec.len;
+        const uint32_t* __restrict__ P = pool + rec.off;
+        double eps = (double)n * cfg.accuracyRate;
+        eps *= eps;
+
+        // 1. approximately the two farthest points (3 rounds)
+        int pos = 0, rs = 0;
+        bool le_eps = false;
+        for (int it = 0; it < 3; it++) {
+            pos = (pos + rs) % n;
+            const IPt sp = unpack_pt(P[pos]);
+            unsigned long long best = 0;
+            for (int j = 1 + lane; j < n; j += 64) {
+                int idx = pos + j;
+                if (idx >= n) idx -= n;
+                const IPt p = unpack_pt(P[idx]);
+                const long long dx = p.x - sp.x, dy = p.y - sp.y;
+                const unsigned long long d = (unsigned long long)(dx * dx + dy * dy);
+                const unsigned long long key = (d << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)j);
+                best = key > best ? key : best;
+            }
+            best = wave_max_u64(best);
+            const unsigned long long maxd = best >> 32;
+            if (maxd > 0) rs = (int)(0xFFFFFFFFu - (unsigned)(best & 0xFFFFFFFFull));
+            le_eps = (double)maxd <= eps;
+        }
+
+        int top = 0, cnt = 0;
+        bool reject = false;
+        if (!le_eps) {
+            const int a = pos % n;
+            const int b = (rs + a) % n;
+            if (lane == 0) {
+                s_stack[0][0] = b; s_stack[0][1] = a;  // right slice
+                s_stack[1][0] = a; s_stack[1][1] = b;  // slice
+            }
+            top = 2;
+        } else {
+            if (lane == 0) s_dst[0] = unpack_pt(P[pos]);
+            cnt = 1;
+        }
+        __syncthreads();
+
+        // 3. recursive split
+        while (top > 0 && !reject) {
+            top--;
+            const int a = s_stack[top][0], b = s_stack[top][1];
+            __syncthreads();
+            const IPt sp = unpack_pt(P[a]);
+            const IPt ep = unpack_pt(P[b]);
+            int first = a + 1;
+            if (first >= n) first = 0;
+            bool le;
+            int split = 0;
+            if (first != b) {
+                int L = b - a - 1;
+                if (L < 0) L += n;
+                const long long dx = ep.x - sp.x, dy = ep.y - sp.y;
+                unsigned long long best = 0;
+                for (int t = lane; t < L; t += 64) {
+                    int idx = first + t;
+                    if (idx >= n) idx -= n;
+                    const IPt p = unpack_pt(P[idx]);
+                    long long d = (long long)(p.y - sp.y) * dx - (long long)(p.x - sp.x) * dy;
+                    if (d < 0) d = -d;
+                    const unsigned long long key = ((unsigned long long)d << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)t);
+                    best = key > best ? key : best;
+                }
+                best = wave_max_u64(best);
+                const double maxd = (double)(best >> 32);
+                if ((best >> 32) > 0) {
+                    split = first + (int)(0xFFFFFFFFu - (unsigned)(best & 0xFFFFFFFFull));
+                    if (split >= n) split -= n;
+                }
+                le = maxd * maxd <= eps * (double)(dx * dx + dy * dy);
+            } else {
+                le = true;
+            }
+            if (le) {
+                if (cnt >= 8) { reject = true; break; }
+                if (lane == 0) s_dst[cnt] = sp;
+                cnt++;
+            } else {
+                if (top + 2 > 16) { reject = true; break; }
+                if (lane == 0) {
+                    s_stack[top][0] = split; s_stack[top][1] = b;
+                    s_stack[top + 1][0] = a; s_stack[top + 1][1] = split;
+                }
+                top += 2;
+            }
+            __syncthreads();
+        }
+        __syncthreads();
+        if (reject || cnt < 4) continue;
+
+        // 4. clean-up pass on <= 8 vertices, then the quad tests; scalar work on lane 0
+        if (lane == 0) {
+            const int count = cnt;
+            int new_count = cnt;
+            auto rd = [&](int& p) { IPt v = s_dst[p]; if (++p >= count) p = 0; return v; };
+            int p = count - 1;
+            IPt start_pt = rd(p);
+            int wpos = p;
+            IPt pt = rd(p);
+            for (int i = 0; i < count && new_count > 2; i++) {
+                IPt end_pt = rd(p);
+                const double dx = end_pt.x - start_pt.x, dy = end_pt.y - start_pt.y;
+                const double dist = fabs((pt.x - start_pt.x) * dy - (pt.y - start_pt.y) * dx);
+                const double sip = (double)(pt.x - start_pt.x) * (end_pt.x - pt.x) + (double)(pt.y - start_pt.y) * (end_pt.y - pt.y);
+                if (dist * dist <= 0.5 * eps * (dx * dx + dy * dy) && dx != 0 && dy != 0 && sip >= 0) {
+                    new_count--;
+                    s_dst[wpos] = start_pt = end_pt;
+                    if (++wpos >= count) wpos = 0;
+                    pt = rd(p);
+                    i++;
+                    continue;
+                }
+                s_dst[wpos] = start_pt = pt;
+                if (++wpos >= count) wpos = 0;
+                pt = end_pt;
+            }
+            bool ok = (new_count == 4);
+            IPt q[4];
+            if (ok) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) q[i] = s_dst[i];
+                // isContourConvex
+                IPt prev = q[2], cur = q[3];
+                int dx0 = cur.x - prev.x, dy0 = cur.y - prev.y, orientation = 0;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    prev = cur;
+                    cur = q[i];
+                    const int dx = cur.x - prev.x, dy = cur.y - prev.y;
+                    const int dxdy0 = dx * dy0, dydx0 = dy * dx0;
+                    orientation |= (dydx0 > dxdy0) ? 1 : ((dydx0 < dxdy0) ? 2 : 3);
+                    dx0 = dx;
+                    dy0 = dy;
+                }
+                if (orientation == 3) ok = false;
+            }
+            if (ok) {
+                const int maxdim = max(cfg.W, cfg.H);
+                double minDistSq = (double)maxdim * maxdim;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const double ddx = (double)(q[j].x - q[(j + 1) & 3].x), ddy = (double)(q[j].y - q[(j + 1) & 3].y);
+                    minDistSq = fmin(minDistSq, ddx * ddx + ddy * ddy);
+                }
+                const double mcd = (double)n * cfg.minCornerDistanceRate;
+                if (minDistSq < mcd * mcd) ok = false;
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if (q[j].x < cfg.minDistToBorder || q[j].y < cfg.minDistToBorder ||
+                        q[j].x > cfg.W - 1 - cfg.minDistToBorder || q[j].y > cfg.H - 1 - cfg.minDistToBorder)
+                        ok = false;
+            }
+            if (ok) {
+                // _reorderCandidatesCorners
+                const double dx1 = q[1].x - q[0].x, dy1 = q[1].y - q[0].y, dx2 = q[2].x - q[0].x, dy2 = q[2].y - q[0].y;
+                if (dx1 * dy2 - dy1 * dx2 < 0.0) { IPt t = q[1]; q[1] = q[3]; q[3] = t; }
+                const int slot = atomicAdd(&qcount[rec.frame], 1);
+                if (slot >= kQuadCap) {
+                    atomicOr(&ctr->overflow, 8u);
+                } else {
+                    QuadRec r;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) { r.c[2 * j] = (int16_t)q[j].x; r.c[2 * j + 1] = (int16_t)q[j].y; }
+                    r.scanKey = rec.scanKey;
+                    r.scale = rec.scale;
+                    r.valid = 0;
+                    r.clen = n;
+                    r.id = -1;
+                    r.rot = 0;
+                    quads[(size_t)rec.frame * kQuadCap + slot] = r;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+void launch_quad_fit(const DetCfg& c, const DetBuffers& b, hipStream_t st) {
+    hipLaunchKernelGGL(k_quad_fit, dim3(256 * 16), dim3(64), 0, st, b.contours, b.contourCap, b.pool, b.quads, b.qcount,
+                       b.counters, c);
+}
+
+}  // namespace camsync

@@ -1,0 +1,186 @@
+// k_subpix.hip — K7: cv::cornerSubPix as ArucoDetector.detectMarkers applies
+// it with CORNER_REFINE_SUBPIX (reference camera_sync/aruco.py:251-264):
+// win = clamp(round(0.3 * moduleSize), 1, cornerRefinementWinSize), zero zone
+// off, criteria (MAX_ITER | EPS, 100, 0.01).
+//
+// One wavefront per corner.  Every iteration the 64 lanes sample the
+// (2 win + 3)^2 bilinear patch into LDS with getRectSubPix's float
+// arithmetic, accumulate the five gradient moments in f64 (lane-strided
+// partial sums + butterfly) and all lanes take the same 2x2 step.  The
+// separable weight table exp(-(i/win)^2) is computed on the host so the
+// weights are those of the CPU path bit for bit.
+#include "internal.h"
+
+namespace camsync {
+
+namespace {
+
+constexpr int kMaxWin = 20;
+constexpr int kMaxPatch = 2 * kMaxWin + 3;
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+// getRectSubPix_8u32f for one output element (i,j) of a pw x pw patch.
+struct PatchGeom {
+    int ipx, ipy;
+    bool fast;
+    float a, b, a11, a12, a21, a22, b1, b2;
+    double s;
+    int rx, rwid;
+};
+
+__device__ __forceinline__ PatchGeom patch_geom(float cx, float cy, int pw, int W, int H) {
+    PatchGeom g;
+    cx -= (pw - 1) * 0.5f;
+    cy -= (pw - 1) * 0.5f;
+    g.ipx = (int)floorf(cx);
+    g.ipy = (int)floorf(cy);
+    g.fast = (0 <= g.ipx && g.ipx + pw < W && 0 <= g.ipy && g.ipy + pw < H);
+    float a = cx - g.ipx, b = cy - g.ipy;
+    if (g.fast) {
+        a = fmaxf(a, 0.0001f);
+        g.a = a;
+        g.b = b;
+        g.a12 = a * (1.f - b);
+        g.a22 = a * b;
+        g.b1 = 1.f - b;
+        g.b2 = b;
+        g.s = (1. - a) / a;
+        g.a11 = g.a21 = 0;
+        g.rx = 0;
+        g.rwid = pw;
+    } else {
+        g.a = a;
+        g.b = b;
+        g.a11 = (1.f - a) * (1.f - b);
+        g.a12 = a * (1.f - b);
+        g.a21 = (1.f - a) * b;
+        g.a22 = a * b;
+        g.b1 = 1.f - b;
+        g.b2 = b;
+        g.s = 0;
+        g.rx = g.ipx >= 0 ? 0 : min(-g.ipx, pw);
+        g.rwid = (g.ipx < W - pw) ? pw : max(W - g.ipx - 1, 0);
+    }
+    return g;
+}
+
+__device__ __forceinline__ float patch_elem(const uint8_t* __restrict__ src, int W, int H, const PatchGeom& g, int i, int j) {
+    if (g.fast) {
+        const uint8_t* p = src + (size_t)(g.ipy + i) * W + g.ipx;
+        const float t = g.a12 * p[j + 1] + g.a22 * p[j + 1 + W];
+        float prev;
+        if (j == 0) {
+            prev = (1 - g.a) * (g.b1 * p[0] + g.b2 * p[W]);
+        } else {
+            const float tp = g.a12 * p[j] + g.a22 * p[j + W];
+            prev = (float)(tp * g.s);
+        }
+        return prev + t;
+    }
+    const int y0 = min(max(g.ipy + i, 0), H - 1), y1 = min(max(g.ipy + i + 1, 0), H - 1);
+    const uint8_t* r0 = src + (size_t)y0 * W;
+    const uint8_t* r1 = src + (size_t)y1 * W;
+    if (j < g.rx) return r0[0] * g.b1 + r1[0] * g.b2;
+    if (j >= g.rwid) return r0[W - 1] * g.b1 + r1[W - 1] * g.b2;
+    const int x0 = g.ipx + j;
+    return r0[x0] * g.a11 + r0[x0 + 1] * g.a12 + r1[x0] * g.a21 + r1[x0 + 1] * g.a22;
+}
+
+__global__ __launch_bounds__(64) void k_subpix(const uint8_t* __restrict__ gray, const MarkerRec* __restrict__ markers,
+                                               unsigned int markerCap, const Counters* __restrict__ ctr,
+                                               const float* __restrict__ rawCorners, float* __restrict__ outCorners,
+                                               const float* __restrict__ expTab, DetCfg cfg) {
+    __shared__ float s_buf[kMaxPatch * kMaxPatch];
+    const int lane = threadIdx.x;
+    const unsigned int nM = min(ctr->nMarkers, markerCap);
+    const int H = cfg.H, W = cfg.W;
+    for (unsigned int job = blockIdx.x; job < nM * 4u; job += gridDim.x) {
+        const MarkerRec mr = markers[job >> 2];
+        const int corner = job & 3;
+        const float* mc = rawCorners + ((size_t)mr.frame * kMaxMarkerOut + mr.slot) * 8;
+        const uint8_t* __restrict__ src = gray + (size_t)mr.frame * H * W;
+        // window from the marker's average module size (unrefined corners)
+        float ms = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float dx = mc[2 * k] - mc[2 * ((k + 1) & 3)], dy = mc[2 * k + 1] - mc[2 * ((k + 1) & 3) + 1];
+            ms += sqrtf(dx * dx + dy * dy);
+        }
+        ms /= (4.f * (float)(cfg.markerSize + 2 * cfg.borderBits));
+        int win = max(1, (int)rint((double)(cfg.relWin * ms)));
+        win = min(win, cfg.subpixWin);
+        win = min(win, kMaxWin);
+        const int ww = 2 * win + 1, pw = ww + 2;
+        const float* __restrict__ et = expTab + win * (2 * kMaxWin + 1);
+        const int max_iters = min(max(cfg.subpixMaxIter, 1), 100);
+        double eps = fmax(cfg.subpixEps, 0.);
+        eps *= eps;
+
+        const float cTx = mc[2 * corner], cTy = mc[2 * corner + 1];
+        float cIx = cTx, cIy = cTy;
+        int iter = 0;
+        double err = 0;
+        do {
+            const PatchGeom g = patch_geom(cIx, cIy, pw, W, H);
+            __syncthreads();
+            for (int e = lane; e < pw * pw; e += 64) {
+                const int i = e / pw, j = e - i * pw;
+                s_buf[e] = patch_elem(src, W, H, g, i, j);
+            }
+            __syncthreads();
+            double a = 0, b = 0, c = 0, bb1 = 0, bb2 = 0;
+            for (int e = lane; e < ww * ww; e += 64) {
+                const int i = e / ww, j = e - i * ww;
+                const float* sp = s_buf + (i + 1) * pw + (j + 1);
+                const double m = (double)(float)(et[i] * et[j]);
+                const double tgx = (double)(sp[1] - sp[-1]);
+                const double tgy = (double)(sp[pw] - sp[-pw]);
+                const double gxx = tgx * tgx * m, gxy = tgx * tgy * m, gyy = tgy * tgy * m;
+                const double px = j - win, py = i - win;
+                a += gxx;
+                b += gxy;
+                c += gyy;
+                bb1 += gxx * px + gxy * py;
+                bb2 += gxy * px + gyy * py;
+            }
+            a = wave_sum_d(a);
+            b = wave_sum_d(b);
+            c = wave_sum_d(c);
+            bb1 = wave_sum_d(bb1);
+            bb2 = wave_sum_d(bb2);
+            const double det = a * c - b * b;
+            if (fabs(det) <= 2.220446049250313e-16 * 2.220446049250313e-16) break;
+            const double scale = 1.0 / det;
+            const float nx = (float)(cIx + c * scale * bb1 - b * scale * bb2);
+            const float ny = (float)(cIy - b * scale * bb1 + a * scale * bb2);
+            err = (double)((nx - cIx) * (nx - cIx) + (ny - cIy) * (ny - cIy));
+            cIx = nx;
+            cIy = ny;
+            if (cIx < 0 || cIx >= W || cIy < 0 || cIy >= H) break;
+        } while (++iter < max_iters && err > eps);
+        if (fabsf(cIx - cTx) > win || fabsf(cIy - cTy) > win) {
+            cIx = cTx;
+            cIy = cTy;
+        }
+        if (lane == 0) {
+            float* dst = outCorners + ((size_t)mr.frame * kMaxMarkerOut + mr.slot) * 8;
+            dst[2 * corner] = cIx;
+            dst[2 * corner + 1] = cIy;
+        }
+    }
+}
+
+}  // namespace
+
+void launch_subpix(const DetCfg& c, const DetBuffers& b, hipStream_t st) {
+    if (!c.subpix) return;
+    hipLaunchKernelGGL(k_subpix, dim3(256 * 8), dim3(64), 0, st, b.gray, b.markers, b.markerCap, b.counters,
+                       b.rawCorners, b.outCorners, b.expTab, c);
+}
+
+}  // namespace camsync

@@ -1,0 +1,277 @@
+// k_threshold.hip — K1+K2: BGR->gray and the multi-window adaptive threshold
+// of ArucoDetector.detectMarkers, fused in one pass (reference call sites:
+// camera_sync/aruco.py:246 cv.cvtColor, :256-264 detectMarkers step 1a).
+//
+// Layout: one workgroup walks a horizontal band of one frame top to bottom.
+// Each of the 256 threads owns 8 adjacent columns (2048 columns per
+// workgroup, 16 of them halo on each side).  Per row the thread reads its 24
+// BGR bytes once (coalesced), converts to luma, writes the gray row, keeps the
+// last 2*rmax+2 gray rows in an LDS ring and maintains the vertical running
+// sums of every window in registers.  The vertical sums are exchanged through
+// LDS and slid horizontally, so every input byte is fetched from HBM once
+// (plus the band/chunk halos) and the three threshold images leave as one
+// packed byte per pixel (bit s = scale s).
+//
+// Integer-exact: luma = (3735 B + 19235 G + 9798 R + 2^14) >> 15;
+// out_s = 1  <=>  round(sum/k^2) >= src + idelta  <=>  2 sum >= (2(src+idelta)-1) k^2
+// (k^2 is odd, so the rounded mean never ties).
+#include "internal.h"
+
+namespace camsync {
+
+namespace {
+
+constexpr int PX = 8;
+constexpr int TPB = 256;
+constexpr int ROWPX = PX * TPB;  // 2048
+constexpr int HALO = 16;         // >= max radius, multiple of PX
+constexpr int CHUNKW = ROWPX - 2 * HALO;
+
+__device__ __forceinline__ uint32_t luma(uint32_t b, uint32_t g, uint32_t r) {
+    return (b * 3735u + g * 19235u + r * 9798u + 16384u) >> 15;
+}
+
+// Load the 8 gray values of columns xbase..xbase+7 (clamped to the image) of
+// row `row` (already clamped) of frame f, converting from BGR when C == 3.
+__device__ __forceinline__ uint2 load_gray8(const uint8_t* __restrict__ in, int C, int W, size_t rowOff,
+                                            int xbase, bool aligned) {
+    uint32_t g[8];
+    if (xbase >= 0 && xbase + 7 < W && aligned) {
+        if (C == 3) {
+            const uint2* p = reinterpret_cast<const uint2*>(in + (rowOff + (size_t)xbase) * 3);
+            uint2 a = p[0], b = p[1], c = p[2];
+            uint32_t w[6] = {a.x, a.y, b.x, b.y, c.x, c.y};
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                int o = 3 * i;
+                uint32_t bb = (w[o >> 2] >> ((o & 3) * 8)) & 255u;
+                uint32_t gg = (w[(o + 1) >> 2] >> (((o + 1) & 3) * 8)) & 255u;
+                uint32_t rr = (w[(o + 2) >> 2] >> (((o + 2) & 3) * 8)) & 255u;
+                g[i] = luma(bb, gg, rr);
+            }
+        } else {
+            return *reinterpret_cast<const uint2*>(in + rowOff + (size_t)xbase);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            int x = min(max(xbase + i, 0), W - 1);
+            if (C == 3) {
+                const uint8_t* p = in + (rowOff + (size_t)x) * 3;
+                g[i] = luma(p[0], p[1], p[2]);
+            } else {
+                g[i] = in[rowOff + (size_t)x];
+            }
+        }
+    }
+    uint2 r;
+    r.x = g[0] | (g[1] << 8) | (g[2] << 16) | (g[3] << 24);
+    r.y = g[4] | (g[5] << 8) | (g[6] << 16) | (g[7] << 24);
+    return r;
+}
+
+__device__ __forceinline__ void unpack8(uint2 v, uint32_t o[8]) {
+    o[0] = v.x & 255u; o[1] = (v.x >> 8) & 255u; o[2] = (v.x >> 16) & 255u; o[3] = v.x >> 24;
+    o[4] = v.y & 255u; o[5] = (v.y >> 8) & 255u; o[6] = (v.y >> 16) & 255u; o[7] = v.y >> 24;
+}
+
+// Sliding horizontal sum of radius R over the exchanged vertical sums.
+// xb points at this scale's row of u16 sums; base = PX*tid.
+template <int R>
+__device__ __forceinline__ void hsum8(const uint16_t* xb, int base, uint32_t out[8]) {
+    // window of pixel i covers [base+i-R, base+i+R]; gather [lo, lo+N) with lo even
+    constexpr int LO = (R + 1) & ~1;             // even offset >= R
+    constexpr int N = 8 + 2 * LO;                // values fetched
+    uint32_t v[N];
+    const uint32_t* p = reinterpret_cast<const uint32_t*>(xb + base - LO);
+#pragma unroll
+    for (int i = 0; i < N / 2; i++) {
+        uint32_t w = p[i];
+        v[2 * i] = w & 0xFFFFu;
+        v[2 * i + 1] = w >> 16;
+    }
+    uint32_t s = 0;
+#pragma unroll
+    for (int j = -R; j <= R; j++) s += v[LO + j];
+    out[0] = s;
+#pragma unroll
+    for (int i = 1; i < 8; i++) {
+        s += v[LO + i + R];
+        s -= v[LO + i - 1 - R];
+        out[i] = s;
+    }
+}
+
+template <int R0, int R1, int R2>
+__global__ __launch_bounds__(TPB) void k_gray_thresh3(const uint8_t* __restrict__ in, int C, uint8_t* __restrict__ gray,
+                                                      uint8_t* __restrict__ bin, int H, int W, int bandH, int idelta) {
+    constexpr int RMAX = R2;
+    constexpr int RING = 2 * RMAX + 2;
+    static_assert(R0 <= R1 && R1 <= R2 && R2 <= HALO - 1, "radii must be sorted and fit the halo");
+    __shared__ __align__(16) uint8_t ring[RING][ROWPX];
+    __shared__ __align__(16) uint16_t xbuf[2][3][ROWPX];
+
+    const int tid = threadIdx.x;
+    const int f = blockIdx.z;
+    const int y0 = blockIdx.y * bandH;
+    const int y1 = min(H, y0 + bandH);
+    const int cx0 = blockIdx.x * CHUNKW;
+    const int xbase = cx0 - HALO + PX * tid;
+    const bool aligned = (W % 8) == 0;
+    const size_t frameOff = (size_t)f * H * W;
+    const bool inOut = (tid >= HALO / PX) && (tid < TPB - HALO / PX) && xbase < W;  // produces output
+    const bool fullOut = inOut && (xbase + 7 < W) && aligned;
+
+    uint32_t V0[8], V1[8], V2[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) V0[i] = V1[i] = V2[i] = 0;
+
+    auto slot = [&](int row) { return (row + 4 * RING) % RING; };
+    auto rowOffOf = [&](int row) { return frameOff + (size_t)min(max(row, 0), H - 1) * W; };
+
+    // warm-up: rows y0-RMAX-1 .. y0+RMAX-1 ; V_k = sum_{d=-r_k-1}^{r_k-1} g(y0+d)
+    for (int d = -RMAX - 1; d <= RMAX - 1; d++) {
+        uint2 g = load_gray8(in, C, W, rowOffOf(y0 + d), xbase, aligned);
+        *reinterpret_cast<uint2*>(&ring[slot(y0 + d)][PX * tid]) = g;
+        uint32_t u[8];
+        unpack8(g, u);
+        if (d >= -R0 - 1 && d <= R0 - 1) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) V0[i] += u[i];
+        }
+        if (d >= -R1 - 1 && d <= R1 - 1) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) V1[i] += u[i];
+        }
+        {
+#pragma unroll
+            for (int i = 0; i < 8; i++) V2[i] += u[i];
+        }
+    }
+
+    uint2 nxt = load_gray8(in, C, W, rowOffOf(y0 + RMAX), xbase, aligned);
+    int buf = 0;
+    for (int y = y0; y < y1; y++) {
+        uint2 gin = nxt;
+        if (y + 1 < y1) nxt = load_gray8(in, C, W, rowOffOf(y + 1 + RMAX), xbase, aligned);
+        *reinterpret_cast<uint2*>(&ring[slot(y + RMAX)][PX * tid]) = gin;
+
+        uint32_t a[8], b[8];
+        // largest window: incoming row is the one just loaded
+        unpack8(gin, a);
+        unpack8(*reinterpret_cast<const uint2*>(&ring[slot(y - R2 - 1)][PX * tid]), b);
+#pragma unroll
+        for (int i = 0; i < 8; i++) V2[i] += a[i] - b[i];
+        unpack8(*reinterpret_cast<const uint2*>(&ring[slot(y + R1)][PX * tid]), a);
+        unpack8(*reinterpret_cast<const uint2*>(&ring[slot(y - R1 - 1)][PX * tid]), b);
+#pragma unroll
+        for (int i = 0; i < 8; i++) V1[i] += a[i] - b[i];
+        unpack8(*reinterpret_cast<const uint2*>(&ring[slot(y + R0)][PX * tid]), a);
+        unpack8(*reinterpret_cast<const uint2*>(&ring[slot(y - R0 - 1)][PX * tid]), b);
+#pragma unroll
+        for (int i = 0; i < 8; i++) V0[i] += a[i] - b[i];
+
+        // exchange vertical sums
+        uint4 w;
+        w.x = V0[0] | (V0[1] << 16); w.y = V0[2] | (V0[3] << 16); w.z = V0[4] | (V0[5] << 16); w.w = V0[6] | (V0[7] << 16);
+        *reinterpret_cast<uint4*>(&xbuf[buf][0][PX * tid]) = w;
+        w.x = V1[0] | (V1[1] << 16); w.y = V1[2] | (V1[3] << 16); w.z = V1[4] | (V1[5] << 16); w.w = V1[6] | (V1[7] << 16);
+        *reinterpret_cast<uint4*>(&xbuf[buf][1][PX * tid]) = w;
+        w.x = V2[0] | (V2[1] << 16); w.y = V2[2] | (V2[3] << 16); w.z = V2[4] | (V2[5] << 16); w.w = V2[6] | (V2[7] << 16);
+        *reinterpret_cast<uint4*>(&xbuf[buf][2][PX * tid]) = w;
+        __syncthreads();
+
+        if (inOut) {
+            const uint2 cen = *reinterpret_cast<const uint2*>(&ring[slot(y)][PX * tid]);
+            uint32_t c[8], s0[8], s1[8], s2[8];
+            unpack8(cen, c);
+            hsum8<R0>(&xbuf[buf][0][0], PX * tid, s0);
+            hsum8<R1>(&xbuf[buf][1][0], PX * tid, s1);
+            hsum8<R2>(&xbuf[buf][2][0], PX * tid, s2);
+            constexpr int K0 = (2 * R0 + 1) * (2 * R0 + 1), K1 = (2 * R1 + 1) * (2 * R1 + 1), K2 = (2 * R2 + 1) * (2 * R2 + 1);
+            uint32_t ob[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                int t2 = 2 * ((int)c[i] + idelta) - 1;
+                uint32_t m = 0;
+                m |= ((int)(2 * s0[i]) >= t2 * K0) ? 1u : 0u;
+                m |= ((int)(2 * s1[i]) >= t2 * K1) ? 2u : 0u;
+                m |= ((int)(2 * s2[i]) >= t2 * K2) ? 4u : 0u;
+                ob[i] = m;
+            }
+            uint2 o;
+            o.x = ob[0] | (ob[1] << 8) | (ob[2] << 16) | (ob[3] << 24);
+            o.y = ob[4] | (ob[5] << 8) | (ob[6] << 16) | (ob[7] << 24);
+            const size_t off = frameOff + (size_t)y * W + xbase;
+            if (fullOut) {
+                *reinterpret_cast<uint2*>(bin + off) = o;
+                if (gray) *reinterpret_cast<uint2*>(gray + off) = cen;
+            } else {
+                for (int i = 0; i < 8; i++)
+                    if (xbase + i < W) {
+                        bin[off + i] = (uint8_t)ob[i];
+                        if (gray) gray[off + i] = (uint8_t)c[i];
+                    }
+            }
+        }
+        buf ^= 1;
+    }
+}
+
+// Generic fallback for detector parameters other than the reference's
+// (windows 3/13/23): direct sums, one thread per pixel.  Correct, not tuned.
+__global__ void k_gray_generic(const uint8_t* __restrict__ in, int C, uint8_t* __restrict__ gray, int H, int W, size_t total) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    if (C == 3) gray[i] = (uint8_t)luma(in[3 * i], in[3 * i + 1], in[3 * i + 2]);
+    else gray[i] = in[i];
+}
+
+__global__ void k_thresh_generic(const uint8_t* __restrict__ gray, uint8_t* __restrict__ bin, DetCfg cfg, int B) {
+    const int H = cfg.H, W = cfg.W;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)B * H * W) return;
+    int x = (int)(i % W);
+    int y = (int)((i / W) % H);
+    const uint8_t* g = gray + (i / ((size_t)W * H)) * (size_t)W * H;
+    int src = g[(size_t)y * W + x];
+    uint32_t m = 0;
+    for (int s = 0; s < cfg.nScales; s++) {
+        int r = cfg.radius[s];
+        int sum = 0;
+        for (int dy = -r; dy <= r; dy++) {
+            int yy = min(max(y + dy, 0), H - 1);
+            for (int dx = -r; dx <= r; dx++) {
+                int xx = min(max(x + dx, 0), W - 1);
+                sum += g[(size_t)yy * W + xx];
+            }
+        }
+        int k2 = (2 * r + 1) * (2 * r + 1);
+        long long t2 = 2 * (src + cfg.idelta) - 1;
+        if (2LL * sum >= t2 * k2) m |= 1u << s;
+    }
+    bin[i] = (uint8_t)m;
+}
+
+}  // namespace
+
+void launch_gray_thresh(const DetCfg& c, const DetBuffers& b, int B, int C, hipStream_t st) {
+    const bool fast = c.nScales == 3 && c.radius[0] == 1 && c.radius[1] == 6 && c.radius[2] == 11;
+    if (fast) {
+        const int chunks = (c.W + CHUNKW - 1) / CHUNKW;
+        // enough workgroups to fill 256 CUs twice, bands no shorter than 32 rows
+        int bands = (1024 + B * chunks - 1) / (B * chunks);
+        bands = max(1, min(bands, (c.H + 31) / 32));
+        int bandH = (c.H + bands - 1) / bands;
+        bands = (c.H + bandH - 1) / bandH;
+        dim3 grid(chunks, bands, B);
+        hipLaunchKernelGGL((k_gray_thresh3<1, 6, 11>), grid, dim3(TPB), 0, st, b.in, C, b.gray, b.bin, c.H, c.W, bandH, c.idelta);
+    } else {
+        size_t total = (size_t)B * c.H * c.W;
+        unsigned blocks = (unsigned)((total + 255) / 256);
+        hipLaunchKernelGGL(k_gray_generic, dim3(blocks), dim3(256), 0, st, b.in, C, b.gray, c.H, c.W, total);
+        hipLaunchKernelGGL(k_thresh_generic, dim3(blocks), dim3(256), 0, st, b.gray, b.bin, c, B);
+    }
+}
+
+}  // namespace camsync

@@ -1,0 +1,218 @@
+/*
+ * camsync.h — C ABI of libcamsync_hip.so, the MI355X (gfx950) implementation of
+ * camera_sync's per-frame vision hot path.
+ *
+ * Each entry point replaces one OpenCV call made by the reference
+ * (6figuress/CameraCalibration, package camera_sync); the citation next to it
+ * is the reference call site it is a drop-in for.  The reference-side binding
+ * is a ctypes stub; cameracalibration_amd/camera_sync/ is the
+ * Python mirror of the reference modules built on that stub.
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 on
+ * success or a negative CAMSYNC_E_* code; camsync_last_error() gives the text.
+ * A ctx owns one HIP stream and all scratch memory; use one ctx per host
+ * thread / GPU.  Calls are synchronous (they return after the stream drained)
+ * unless stated.  Buffers flagged `on_device` are device pointers on the
+ * ctx's GPU (e.g. torch tensor .data_ptr()); otherwise host pointers.
+ */
+#ifndef CAMSYNC_H
+#define CAMSYNC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CAMSYNC_OK 0
+#define CAMSYNC_E_ARG (-1)      /* bad argument */
+#define CAMSYNC_E_HIP (-2)      /* HIP runtime error */
+#define CAMSYNC_E_CAPACITY (-3) /* a per-frame scratch list overflowed */
+#define CAMSYNC_E_NODEVICE (-4) /* no usable GPU */
+#define CAMSYNC_E_NUMERIC (-5)  /* solver failed (reference raises "Could not solve PnP") */
+
+typedef struct camsync_ctx camsync_ctx;
+
+/* cv.aruco.DetectorParameters as the reference configures it
+ * (camera_sync/aruco.py:249-254); defaults of OpenCV 4.11 for the rest. */
+typedef struct camsync_params {
+    int32_t adaptiveThreshWinSizeMin;      /* 3  */
+    int32_t adaptiveThreshWinSizeMax;      /* 23 */
+    int32_t adaptiveThreshWinSizeStep;     /* 10 */
+    double  adaptiveThreshConstant;        /* 7  */
+    double  minMarkerPerimeterRate;        /* 0.03 */
+    double  maxMarkerPerimeterRate;        /* 4.0  */
+    double  polygonalApproxAccuracyRate;   /* 0.03 */
+    double  minCornerDistanceRate;         /* 0.05 */
+    int32_t minDistanceToBorder;           /* 3 */
+    int32_t markerBorderBits;              /* 1 */
+    double  minMarkerDistanceRate;         /* 0.125 */
+    float   minGroupDistance;              /* 0.21 */
+    int32_t cornerRefinementMethod;        /* 1 = CORNER_REFINE_SUBPIX (aruco.py:251) */
+    int32_t cornerRefinementWinSize;       /* 20  (aruco.py:252) */
+    float   relativeCornerRefinmentWinSize;/* 0.3 */
+    int32_t cornerRefinementMaxIterations; /* 100 (aruco.py:254) */
+    double  cornerRefinementMinAccuracy;   /* 0.01 (aruco.py:253) */
+    int32_t perspectiveRemovePixelPerCell; /* 4 */
+    double  perspectiveRemoveIgnoredMarginPerCell; /* 0.13 */
+    double  maxErroneousBitsInBorderRate;  /* 0.35 */
+    double  minOtsuStdDev;                 /* 5.0 */
+    double  errorCorrectionRate;           /* 0.6 */
+} camsync_params;
+
+/* ---- context -------------------------------------------------------- */
+
+/* Library / device probe: number of visible GPUs, <0 on error. */
+int camsync_device_count(void);
+
+/* Create a context on `device` sized for frames up to max_h x max_w and
+ * chunks of max_batch frames (larger batches are processed in chunks).
+ * Replaces the per-call construction of cv.aruco.ArucoDetector
+ * (aruco.py:247-262). */
+int camsync_create(camsync_ctx** out, int device, int max_h, int max_w, int max_batch);
+void camsync_destroy(camsync_ctx* ctx);
+const char* camsync_last_error(const camsync_ctx* ctx);
+
+/* cv.aruco.DetectorParameters() (aruco.py:249-254). */
+void camsync_default_params(camsync_params* p);
+int camsync_set_params(camsync_ctx* ctx, const camsync_params* p);
+int camsync_get_params(const camsync_ctx* ctx, camsync_params* p);
+
+/* cv.aruco.getPredefinedDictionary (aruco.py:247): n codes, each the
+ * marker_size*marker_size inner bits of rotation 0, row-major, MSB first.
+ * Rotations are derived on device.  marker_size <= 4 (16-bit codes). */
+int camsync_set_dictionary(camsync_ctx* ctx, const uint16_t* codes, int n, int marker_size,
+                           int max_correction_bits);
+
+/* ---- detection ------------------------------------------------------ */
+
+/* cv.cvtColor(BGR2GRAY) + the adaptiveThreshold passes of detectMarkers
+ * (aruco.py:246, :256-264 step 1a).  frames u8 [B,H,W,C], C in {1,3}.
+ * gray_out u8 [B,H,W]; bin_out u8 [B,H,W], bit s = threshold image of scale s
+ * (window = WinSizeMin + s*Step).  Either output may be NULL.  Outputs follow
+ * `on_device` like the input. */
+int camsync_gray_threshold(camsync_ctx* ctx, const uint8_t* frames, int on_device,
+                           int B, int H, int W, int C, uint8_t* gray_out, uint8_t* bin_out);
+
+/* cv.cvtColor + ArucoDetector.detectMarkers for a batch (aruco.py:246-264).
+ * ids i32 [B,max_markers], corners f32 [B,max_markers,4,2], counts i32 [B];
+ * rejected f32 [B,max_rejected,4,2] and rej_counts i32 [B] may be NULL.
+ * Marker order per frame = the reference detector's output order.
+ * Outputs are host pointers. */
+int camsync_detect_batch(camsync_ctx* ctx, const uint8_t* frames, int on_device,
+                         int B, int H, int W, int C,
+                         int max_markers, int32_t* ids, float* corners, int32_t* counts,
+                         int max_rejected, float* rejected, int32_t* rej_counts);
+
+/* Intermediate results of the last camsync_detect_batch chunk, for parity
+ * tests: what = 0 contour candidates examined, 1 contours kept by the perimeter
+ * filter, 2 quads (out: per quad 8 f32 corners, then scale, scan key, contour
+ * length as f32-encoded ints are NOT used — see layout in DESIGN.md).
+ * Returns the element count, or <0. */
+int camsync_debug_counts(camsync_ctx* ctx, int frame, int32_t out[8]);
+int camsync_debug_quads(camsync_ctx* ctx, int frame, int max_quads, float* corners,
+                        int32_t* scale, int32_t* scan_key, int32_t* contour_len,
+                        int32_t* id, int32_t* rot);
+int camsync_debug_contours(camsync_ctx* ctx, int frame, int max_contours, int32_t* scale,
+                           int32_t* start_key, int32_t* is_hole, int32_t* length);
+
+/* ---- pose ----------------------------------------------------------- */
+
+/* cv.solvePnP(ITERATIVE) followed by cv.solvePnPRefineLM, batched
+ * (aruco.py:368-384), plus the MAE/RMSE of aruco.py:386-400.
+ * obj f32 [B,N,3], img f32 [B,N,2], npts i32 [B] (<= N), K f64 [B or 1,3,3],
+ * dist f64 [B or 1, ndist] (ndist <= 8: k1,k2,p1,p2,k3,k4,k5,k6),
+ * per_frame_cam: 1 if K/dist are per frame.  Outputs (host): rvec,tvec f64
+ * [B,3], ok u8 [B], mae,rmse f64 [B] (may be NULL). */
+int camsync_pnp_batch(camsync_ctx* ctx, const float* obj, const float* img, const int32_t* npts,
+                      int B, int N, const double* K, const double* dist, int ndist,
+                      int per_frame_cam, double* rvec, double* tvec, uint8_t* ok,
+                      double* mae, double* rmse);
+
+/* cv.solvePnP(SOLVEPNP_IPPE_SQUARE) for B squares (aruco.py:97-117 inside
+ * estimate_pose_single_markers).  corners f32 [B,4,2] (TL,TR,BR,BL),
+ * size f64 [B], K/dist as above. */
+int camsync_ippe_square_batch(camsync_ctx* ctx, const float* corners, const double* size, int B,
+                              const double* K, const double* dist, int ndist, int per_frame_cam,
+                              double* rvec, double* tvec, uint8_t* ok);
+
+/* detectAruco + anchor gather + PnP fused on device: the body of processAruco
+ * up to camera.updateWorldPosition (aruco.py:305-336) for B frames.
+ * anchors: n_anchor ids with their 4 object corners f32 [n_anchor,4,3]
+ * (Aruco.getCornersAsList order, aruco.py:58-67).  Frames that see < 1 anchor
+ * (fewer than 4 points) get pose_ok = 0 (processAruco returns False / raises).
+ * Detection outputs as camsync_detect_batch. */
+int camsync_detect_pnp_batch(camsync_ctx* ctx, const uint8_t* frames, int on_device,
+                             int B, int H, int W, int C,
+                             const int32_t* anchor_ids, const float* anchor_obj, int n_anchor,
+                             const double* K, const double* dist, int ndist, int per_frame_cam,
+                             int max_markers, int32_t* ids, float* corners, int32_t* counts,
+                             double* rvec, double* tvec, uint8_t* pose_ok, double* mae, double* rmse);
+
+/* Same pipeline, inputs already resident on the GPU and results left on the
+ * GPU (no host copies, returns after the stream drained): the benchmark /
+ * serving entry point.  d_* are device pointers laid out as above. */
+int camsync_detect_pnp_resident(camsync_ctx* ctx, const uint8_t* d_frames, int B, int H, int W, int C,
+                                const int32_t* anchor_ids, const float* anchor_obj, int n_anchor,
+                                const double* K, const double* dist, int ndist,
+                                int max_markers, int32_t* d_ids, float* d_corners, int32_t* d_counts,
+                                double* d_rvec, double* d_tvec, uint8_t* d_pose_ok);
+
+/* ---- calibration ---------------------------------------------------- */
+
+/* cv.calibrateCamera(objpoints, imgpoints, size, None, None)
+ * (camera.py:61-63).  obj f32 [V,P,3], img f32 [V,P,2]; flags bit0 =
+ * CALIB_RATIONAL_MODEL.  K f64 [9], dist f64 [5 or 8], rvecs/tvecs f64 [V,3]
+ * (may be NULL), rms f64, iters i32 (LM iterations run). */
+int camsync_calibrate(camsync_ctx* ctx, const float* obj, const float* img, int V, int P,
+                      int W, int H, int flags, int max_iter,
+                      double* K, double* dist, double* rvecs, double* tvecs,
+                      double* rms, int32_t* iters);
+
+/* Multi-GPU calibration building blocks (one rank per GPU, views sharded
+ * contiguously).  The caller owns the LM loop (cvCalibrateCamera2Internal's
+ * CvLevMarq::updateAlt state machine) and all-reduces (sum) the small record
+ * between accumulate and step; cameracalibration_amd/camera_sync/
+ * calibrate_dist.py is the torch.distributed (RCCL) driver, camsync_calibrate
+ * the single-GPU one.
+ *   camsync_calib_begin       upload this rank's views (obj f32 [V,P,3], img
+ *                             f32 [V,P,2], P <= 64); flags bit0 = rational
+ *   camsync_calib_focal_acc   this rank's sums for the closed-form focal
+ *                             initialisation (cvInitIntrinsicParams2D):
+ *                             [a00 a01 a11 b0 b1 nviews], to be summed over ranks
+ *   camsync_calib_set_intrinsics  set fx fy cx cy k1 k2 p1 p2 k3 k4 k5 k6; with
+ *                             init_extrinsics, also initialise every local
+ *                             view's pose (cvFindExtrinsicCameraParams2)
+ *   camsync_calib_accumulate  acc f64 [ni*ni + ni + 1] = this rank's Schur
+ *                             complement, reduced right-hand side and squared
+ *                             error at the current parameters, damping lambda
+ *   camsync_calib_solve       host: solve the all-reduced ni x ni system
+ *   camsync_calib_step        apply the intrinsic delta, back-substitute the
+ *                             local extrinsics into the trial parameters and
+ *                             return the local squared error there
+ *   camsync_calib_accept      trial parameters become current */
+int camsync_calib_begin(camsync_ctx* ctx, const float* obj, const float* img, int V, int P, int flags);
+int camsync_calib_focal_acc(camsync_ctx* ctx, int W, int H, double acc6[6]);
+int camsync_calib_set_intrinsics(camsync_ctx* ctx, const double intr[12], int init_extrinsics);
+int camsync_calib_accumulate(camsync_ctx* ctx, double lambda, double* acc, int acc_on_device);
+int camsync_calib_solve(const double* acc, int ni, double* delta);
+int camsync_calib_step(camsync_ctx* ctx, const double* delta, double* err_out);
+int camsync_calib_accept(camsync_ctx* ctx);
+int camsync_calib_get(camsync_ctx* ctx, double intr[12], double* rvecs, double* tvecs);
+int camsync_calib_n_intrinsics(const camsync_ctx* ctx);
+
+/* ---- measurement ---------------------------------------------------- */
+
+/* Accumulated hipEvent time (ms) and launch count per stage since the last
+ * reset: stage 0 gray+threshold, 1 contour starts, 2 trace, 3 quad fit,
+ * 4 identify, 5 per-frame select, 6 subpix, 7 pnp, 8 whole chunk.  Timing is
+ * only collected after camsync_enable_timers(ctx, 1). */
+#define CAMSYNC_N_STAGES 9
+int camsync_enable_timers(camsync_ctx* ctx, int on);
+int camsync_get_timers(camsync_ctx* ctx, double ms[CAMSYNC_N_STAGES], int64_t launches[CAMSYNC_N_STAGES]);
+int camsync_reset_timers(camsync_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
