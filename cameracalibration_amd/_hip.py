@@ -1,0 +1,383 @@
+"""ctypes binding of libcamsync_hip.so (include/camsync.h).
+
+This is the only way the package reaches the GPU.  There is no CPU fallback:
+if the library is missing, or no GPU is visible, the calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+from . import _dict4x4_50 as _dict
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcamsync_hip.so")
+
+N_STAGES = 9
+STAGE_NAMES = ("gray_threshold", "contour_starts", "trace", "quad_fit", "identify", "select", "subpix", "pnp", "total")
+
+
+class CamsyncError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libcamsync_hip error {code}: {msg}")
+        self.code = code
+
+
+class Params(C.Structure):
+    """camsync_params — cv.aruco.DetectorParameters as aruco.py:249-254 sets it."""
+
+    _fields_ = [
+        ("adaptiveThreshWinSizeMin", C.c_int32),
+        ("adaptiveThreshWinSizeMax", C.c_int32),
+        ("adaptiveThreshWinSizeStep", C.c_int32),
+        ("adaptiveThreshConstant", C.c_double),
+        ("minMarkerPerimeterRate", C.c_double),
+        ("maxMarkerPerimeterRate", C.c_double),
+        ("polygonalApproxAccuracyRate", C.c_double),
+        ("minCornerDistanceRate", C.c_double),
+        ("minDistanceToBorder", C.c_int32),
+        ("markerBorderBits", C.c_int32),
+        ("minMarkerDistanceRate", C.c_double),
+        ("minGroupDistance", C.c_float),
+        ("cornerRefinementMethod", C.c_int32),
+        ("cornerRefinementWinSize", C.c_int32),
+        ("relativeCornerRefinmentWinSize", C.c_float),
+        ("cornerRefinementMaxIterations", C.c_int32),
+        ("cornerRefinementMinAccuracy", C.c_double),
+        ("perspectiveRemovePixelPerCell", C.c_int32),
+        ("perspectiveRemoveIgnoredMarginPerCell", C.c_double),
+        ("maxErroneousBitsInBorderRate", C.c_double),
+        ("minOtsuStdDev", C.c_double),
+        ("errorCorrectionRate", C.c_double),
+    ]
+
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+def load_library() -> C.CDLL:
+    """Load libcamsync_hip.so; raises if it has not been built."""
+    global _lib
+    with _lib_lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: build it with `make -C cameracalibration_amd/csrc` "
+                "(or __graft_entry__.build()); there is no CPU fallback"
+            )
+        lib = C.CDLL(LIB_PATH)
+        vp, i32, dbl = C.c_void_p, C.c_int, C.c_double
+        lib.camsync_device_count.restype = i32
+        lib.camsync_create.argtypes = [C.POINTER(vp), i32, i32, i32, i32]
+        lib.camsync_destroy.argtypes = [vp]
+        lib.camsync_destroy.restype = None
+        lib.camsync_last_error.argtypes = [vp]
+        lib.camsync_last_error.restype = C.c_char_p
+        lib.camsync_default_params.argtypes = [C.POINTER(Params)]
+        lib.camsync_default_params.restype = None
+        lib.camsync_set_params.argtypes = [vp, C.POINTER(Params)]
+        lib.camsync_get_params.argtypes = [vp, C.POINTER(Params)]
+        lib.camsync_set_dictionary.argtypes = [vp, vp, i32, i32, i32]
+        lib.camsync_gray_threshold.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp]
+        lib.camsync_detect_batch.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, i32, vp, vp]
+        lib.camsync_debug_counts.argtypes = [vp, i32, vp]
+        lib.camsync_debug_quads.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp]
+        lib.camsync_debug_contours.argtypes = [vp, i32, i32, vp, vp, vp, vp]
+        lib.camsync_pnp_batch.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, vp, vp, vp]
+        lib.camsync_ippe_square_batch.argtypes = [vp, vp, vp, i32, vp, vp, i32, i32, vp, vp, vp]
+        lib.camsync_detect_pnp_batch.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp, i32, i32,
+                                                 i32, vp, vp, vp, vp, vp, vp, vp, vp]
+        lib.camsync_detect_pnp_resident.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, i32, vp, vp, i32,
+                                                    i32, vp, vp, vp, vp, vp, vp]
+        lib.camsync_calibrate.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp]
+        lib.camsync_calib_begin.argtypes = [vp, vp, vp, i32, i32, i32]
+        lib.camsync_calib_focal_acc.argtypes = [vp, i32, i32, vp]
+        lib.camsync_calib_set_intrinsics.argtypes = [vp, vp, i32]
+        lib.camsync_calib_accumulate.argtypes = [vp, dbl, vp, i32]
+        lib.camsync_calib_solve.argtypes = [vp, i32, vp]
+        lib.camsync_calib_step.argtypes = [vp, vp, vp]
+        lib.camsync_calib_accept.argtypes = [vp]
+        lib.camsync_calib_get.argtypes = [vp, vp, vp, vp]
+        lib.camsync_calib_n_intrinsics.argtypes = [vp]
+        lib.camsync_enable_timers.argtypes = [vp, i32]
+        lib.camsync_get_timers.argtypes = [vp, vp, vp]
+        lib.camsync_reset_timers.argtypes = [vp]
+        _lib = lib
+        return lib
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _cam(K, dist, B):
+    """Normalise camera matrix / distortion to contiguous f64 and report layout."""
+    K = np.ascontiguousarray(K, dtype=np.float64)
+    per_frame = 1 if K.ndim == 3 else 0
+    K = K.reshape(-1, 9)
+    if per_frame and K.shape[0] != B:
+        raise ValueError("per-frame camera matrices must have one entry per frame")
+    if dist is None:
+        d = np.zeros((K.shape[0], 0), dtype=np.float64)
+    else:
+        d = np.ascontiguousarray(dist, dtype=np.float64).reshape(K.shape[0], -1)
+    if d.shape[1] > 8:
+        if np.any(d[:, 8:] != 0):
+            raise ValueError("thin-prism / tilt distortion terms are not supported")
+        d = np.ascontiguousarray(d[:, :8])
+    return K, d, per_frame
+
+
+class Context:
+    """One camsync_ctx: a GPU, a stream and the detection scratch."""
+
+    def __init__(self, max_h: int, max_w: int, max_batch: int = 8, device: int = 0, dictionary=None):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        rc = self._lib.camsync_create(C.byref(self._h), device, max_h, max_w, max_batch)
+        if rc != 0:
+            msg = self._lib.camsync_last_error(self._h).decode() if self._h else "no usable GPU"
+            if self._h:
+                self._lib.camsync_destroy(self._h)
+                self._h = C.c_void_p()
+            raise CamsyncError(rc, msg)
+        self.max_h, self.max_w, self.max_batch, self.device = max_h, max_w, max_batch, device
+        codes = _dict.CODES if dictionary is None else np.ascontiguousarray(dictionary, dtype=np.uint16)
+        self._check(self._lib.camsync_set_dictionary(self._h, _ptr(codes), len(codes), _dict.MARKER_SIZE,
+                                                     _dict.MAX_CORRECTION_BITS))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.camsync_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise CamsyncError(rc, self._lib.camsync_last_error(self._h).decode())
+
+    # -- parameters ----------------------------------------------------
+    def default_params(self) -> Params:
+        p = Params()
+        self._lib.camsync_default_params(C.byref(p))
+        return p
+
+    def set_params(self, p: Params):
+        self._check(self._lib.camsync_set_params(self._h, C.byref(p)))
+
+    def get_params(self) -> Params:
+        p = Params()
+        self._check(self._lib.camsync_get_params(self._h, C.byref(p)))
+        return p
+
+    # -- detection -----------------------------------------------------
+    @staticmethod
+    def _frames(frames):
+        f = np.ascontiguousarray(frames, dtype=np.uint8)
+        if f.ndim == 2:
+            f = f[None, :, :, None]
+        elif f.ndim == 3:
+            # (H,W,C) single frame or (B,H,W) gray batch: channel counts are 1 or 3
+            f = f[None] if f.shape[-1] in (1, 3) else f[..., None]
+        if f.ndim != 4:
+            raise ValueError("frames must be [B,H,W,C], [H,W,C], [B,H,W] or [H,W]")
+        return f
+
+    def gray_threshold(self, frames):
+        f = self._frames(frames)
+        B, H, W, Cn = f.shape
+        gray = np.empty((B, H, W), np.uint8)
+        binp = np.empty((B, H, W), np.uint8)
+        self._check(self._lib.camsync_gray_threshold(self._h, _ptr(f), 0, B, H, W, Cn, _ptr(gray), _ptr(binp)))
+        return gray, binp
+
+    def detect(self, frames, max_markers: int = 64, max_rejected: int = 256):
+        """Returns (ids [B,M], corners [B,M,4,2], counts [B], rejected [B,R,4,2], rej_counts [B])."""
+        f = self._frames(frames)
+        B, H, W, Cn = f.shape
+        ids = np.full((B, max_markers), -1, np.int32)
+        corners = np.zeros((B, max_markers, 4, 2), np.float32)
+        counts = np.zeros(B, np.int32)
+        rej = np.zeros((B, max_rejected, 4, 2), np.float32)
+        rejc = np.zeros(B, np.int32)
+        self._check(self._lib.camsync_detect_batch(self._h, _ptr(f), 0, B, H, W, Cn, max_markers, _ptr(ids),
+                                                   _ptr(corners), _ptr(counts), max_rejected, _ptr(rej), _ptr(rejc)))
+        return ids, corners, counts, rej, rejc
+
+    def debug_counts(self, frame=0):
+        out = np.zeros(8, np.int32)
+        self._check(self._lib.camsync_debug_counts(self._h, frame, _ptr(out)))
+        return dict(candidates=int(out[0]), contours=int(out[1]), points=int(out[2]), markers=int(out[3]),
+                    overflow=int(out[4]), quads=int(out[5]), batch=int(out[6]))
+
+    def debug_quads(self, frame=0, cap=256):
+        c = np.zeros((cap, 4, 2), np.float32)
+        sc, key, ln, idv, rot = (np.zeros(cap, np.int32) for _ in range(5))
+        n = self._lib.camsync_debug_quads(self._h, frame, cap, _ptr(c), _ptr(sc), _ptr(key), _ptr(ln), _ptr(idv), _ptr(rot))
+        if n < 0:
+            self._check(n)
+        n = min(n, cap)
+        return dict(corners=c[:n], scale=sc[:n], scan_key=key[:n], contour_len=ln[:n], id=idv[:n], rot=rot[:n])
+
+    def debug_contours(self, frame=0, cap=8192):
+        sc, key, hole, ln = (np.zeros(cap, np.int32) for _ in range(4))
+        n = self._lib.camsync_debug_contours(self._h, frame, cap, _ptr(sc), _ptr(key), _ptr(hole), _ptr(ln))
+        if n < 0:
+            self._check(n)
+        n = min(n, cap)
+        return dict(scale=sc[:n], start_key=key[:n], is_hole=hole[:n], length=ln[:n])
+
+    # -- pose ----------------------------------------------------------
+    def pnp(self, obj, img, npts, K, dist):
+        obj = np.ascontiguousarray(obj, dtype=np.float32)
+        img = np.ascontiguousarray(img, dtype=np.float32)
+        B, N = obj.shape[0], obj.shape[1]
+        npts = np.ascontiguousarray(npts, dtype=np.int32)
+        K, d, per_frame = _cam(K, dist, B)
+        rvec = np.zeros((B, 3)); tvec = np.zeros((B, 3)); ok = np.zeros(B, np.uint8)
+        mae = np.zeros(B); rmse = np.zeros(B)
+        self._check(self._lib.camsync_pnp_batch(self._h, _ptr(obj), _ptr(img), _ptr(npts), B, N, _ptr(K), _ptr(d),
+                                                d.shape[1], per_frame, _ptr(rvec), _ptr(tvec), _ptr(ok), _ptr(mae), _ptr(rmse)))
+        return rvec, tvec, ok, mae, rmse
+
+    def ippe_square(self, corners, size, K, dist):
+        corners = np.ascontiguousarray(corners, dtype=np.float32).reshape(-1, 4, 2)
+        B = corners.shape[0]
+        size = np.ascontiguousarray(np.broadcast_to(np.asarray(size, dtype=np.float64), (B,)))
+        K, d, per_frame = _cam(K, dist, B)
+        rvec = np.zeros((B, 3)); tvec = np.zeros((B, 3)); ok = np.zeros(B, np.uint8)
+        self._check(self._lib.camsync_ippe_square_batch(self._h, _ptr(corners), _ptr(size), B, _ptr(K), _ptr(d),
+                                                        d.shape[1], per_frame, _ptr(rvec), _ptr(tvec), _ptr(ok)))
+        return rvec, tvec, ok
+
+    def detect_pnp(self, frames, anchor_ids, anchor_obj, K, dist, max_markers: int = 64):
+        f = self._frames(frames)
+        B, H, W, Cn = f.shape
+        anchor_ids = np.ascontiguousarray(anchor_ids, dtype=np.int32)
+        anchor_obj = np.ascontiguousarray(anchor_obj, dtype=np.float32).reshape(len(anchor_ids), 4, 3)
+        K, d, per_frame = _cam(K, dist, B)
+        ids = np.full((B, max_markers), -1, np.int32)
+        corners = np.zeros((B, max_markers, 4, 2), np.float32)
+        counts = np.zeros(B, np.int32)
+        rvec = np.zeros((B, 3)); tvec = np.zeros((B, 3)); ok = np.zeros(B, np.uint8)
+        mae = np.zeros(B); rmse = np.zeros(B)
+        self._check(self._lib.camsync_detect_pnp_batch(
+            self._h, _ptr(f), 0, B, H, W, Cn, _ptr(anchor_ids), _ptr(anchor_obj), len(anchor_ids), _ptr(K), _ptr(d),
+            d.shape[1], per_frame, max_markers, _ptr(ids), _ptr(corners), _ptr(counts), _ptr(rvec), _ptr(tvec),
+            _ptr(ok), _ptr(mae), _ptr(rmse)))
+        return ids, corners, counts, rvec, tvec, ok, mae, rmse
+
+    def detect_pnp_resident(self, d_frames_ptr, B, H, W, Cn, anchor_ids, anchor_obj, K, dist, max_markers,
+                            d_ids, d_corners, d_counts, d_rvec, d_tvec, d_ok):
+        """All d_* are raw device pointers (ints), e.g. torch tensor .data_ptr()."""
+        anchor_ids = np.ascontiguousarray(anchor_ids, dtype=np.int32)
+        anchor_obj = np.ascontiguousarray(anchor_obj, dtype=np.float32)
+        K, d, _ = _cam(K, dist, 1)
+        self._check(self._lib.camsync_detect_pnp_resident(
+            self._h, C.c_void_p(d_frames_ptr), B, H, W, Cn, _ptr(anchor_ids), _ptr(anchor_obj), len(anchor_ids),
+            _ptr(K), _ptr(d), d.shape[1], max_markers, C.c_void_p(d_ids), C.c_void_p(d_corners), C.c_void_p(d_counts),
+            C.c_void_p(d_rvec), C.c_void_p(d_tvec), C.c_void_p(d_ok)))
+
+    # -- calibration ---------------------------------------------------
+    def calibrate(self, obj, img, image_size, rational=False, max_iter=30):
+        obj = np.ascontiguousarray(obj, dtype=np.float32)
+        img = np.ascontiguousarray(img, dtype=np.float32).reshape(obj.shape[0], obj.shape[1], 2)
+        V, P = obj.shape[:2]
+        W, H = image_size
+        K = np.zeros((3, 3)); dist = np.zeros(8 if rational else 5)
+        rvecs = np.zeros((V, 3)); tvecs = np.zeros((V, 3))
+        rms = C.c_double(0); iters = C.c_int32(0)
+        self._check(self._lib.camsync_calibrate(self._h, _ptr(obj), _ptr(img), V, P, W, H, 1 if rational else 0, max_iter,
+                                                _ptr(K), _ptr(dist), _ptr(rvecs), _ptr(tvecs), C.byref(rms), C.byref(iters)))
+        return rms.value, K, dist, rvecs, tvecs, iters.value
+
+    def calib_begin(self, obj, img, rational=False):
+        obj = np.ascontiguousarray(obj, dtype=np.float32)
+        V = obj.shape[0]
+        P = obj.shape[1] if V else (img.shape[1] if hasattr(img, "shape") and len(img.shape) > 1 else 49)
+        img = np.ascontiguousarray(img, dtype=np.float32).reshape(V, P, 2)
+        self._check(self._lib.camsync_calib_begin(self._h, _ptr(obj) if V else None, _ptr(img) if V else None, V, P,
+                                                  1 if rational else 0))
+        return self._lib.camsync_calib_n_intrinsics(self._h)
+
+    def calib_focal_acc(self, W, H):
+        acc = np.zeros(6)
+        self._check(self._lib.camsync_calib_focal_acc(self._h, W, H, _ptr(acc)))
+        return acc
+
+    def calib_set_intrinsics(self, intr, init_extrinsics):
+        intr = np.ascontiguousarray(intr, dtype=np.float64)
+        assert intr.size == 12
+        self._check(self._lib.camsync_calib_set_intrinsics(self._h, _ptr(intr), 1 if init_extrinsics else 0))
+
+    def calib_accumulate(self, lam, ni):
+        acc = np.zeros(ni * ni + ni + 1)
+        self._check(self._lib.camsync_calib_accumulate(self._h, float(lam), _ptr(acc), 0))
+        return acc
+
+    def calib_accumulate_device(self, lam, d_acc_ptr):
+        self._check(self._lib.camsync_calib_accumulate(self._h, float(lam), C.c_void_p(d_acc_ptr), 1))
+
+    def calib_solve(self, acc, ni):
+        acc = np.ascontiguousarray(acc, dtype=np.float64)
+        delta = np.zeros(12)
+        rc = self._lib.camsync_calib_solve(_ptr(acc), ni, _ptr(delta))
+        if rc != 0:
+            raise CamsyncError(rc, "intrinsic block is singular")
+        return delta
+
+    def calib_step(self, delta):
+        delta = np.ascontiguousarray(delta, dtype=np.float64)
+        err = C.c_double(0)
+        self._check(self._lib.camsync_calib_step(self._h, _ptr(delta), C.byref(err)))
+        return err.value
+
+    def calib_accept(self):
+        self._check(self._lib.camsync_calib_accept(self._h))
+
+    def calib_get(self, V):
+        intr = np.zeros(12); rv = np.zeros((max(V, 1), 3)); tv = np.zeros((max(V, 1), 3))
+        self._check(self._lib.camsync_calib_get(self._h, _ptr(intr), _ptr(rv), _ptr(tv)))
+        return intr, rv[:V], tv[:V]
+
+    # -- timers --------------------------------------------------------
+    def enable_timers(self, on=True):
+        self._check(self._lib.camsync_enable_timers(self._h, 1 if on else 0))
+
+    def reset_timers(self):
+        self._check(self._lib.camsync_reset_timers(self._h))
+
+    def timers(self):
+        ms = np.zeros(N_STAGES); n = np.zeros(N_STAGES, np.int64)
+        self._check(self._lib.camsync_get_timers(self._h, _ptr(ms), _ptr(n)))
+        return {STAGE_NAMES[i]: (float(ms[i]), int(n[i])) for i in range(N_STAGES)}
+
+
+_default_ctx = {}
+_ctx_lock = threading.Lock()
+
+
+def get_context(h: int, w: int, batch: int = 1, device: int = 0) -> Context:
+    """A cached context large enough for (batch, h, w) frames on `device`."""
+    with _ctx_lock:
+        key = device
+        ctx = _default_ctx.get(key)
+        if ctx is None or ctx.max_h < h or ctx.max_w < w or ctx.max_batch < batch:
+            if ctx is not None:
+                ctx.close()
+            ctx = Context(max(h, ctx.max_h if ctx else 0), max(w, ctx.max_w if ctx else 0),
+                          max(batch, ctx.max_batch if ctx else 0), device)
+            _default_ctx[key] = ctx
+        return ctx

@@ -1,0 +1,236 @@
+"""GPU parity tests: libcamsync_hip (through the C ABI) against the CPU oracle
+and the reference's golden vectors.  Run on the MI355X box with -m gpu."""
+import numpy as np
+import pytest
+
+from tests import _data, _oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from cameracalibration_amd import _hip
+    c = _hip.Context(1080, 1920, max_batch=4)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def synth_frames():
+    from cameracalibration_amd import synth
+    K, _ = _data.calibration("Logitec_robot_1920-1080_10.npz")
+    return [synth.v1_frame(i, K, ss=2)[0].numpy() for i in range(3)]
+
+
+def _oracle_bin(gray):
+    return [orc.adaptive_threshold(gray, w) for w in (3, 13, 23)]
+
+
+@pytest.mark.parametrize("name", ["pic_1.png", "pic_2.png"])
+def test_gray_threshold_photos(ctx, name):
+    bgr = _data.load_bgr(name)
+    gray, binp = ctx.gray_threshold(bgr)
+    og = orc.bgr2gray(bgr)
+    assert np.array_equal(gray[0], og)
+    for s, ob in enumerate(_oracle_bin(og)):
+        got = ((binp[0] >> s) & 1) * 255
+        assert np.array_equal(got, ob), f"scale {s}: {np.count_nonzero(got != ob)} pixels differ"
+
+
+def test_gray_threshold_batch_and_gray_input(ctx, synth_frames):
+    batch = np.stack(synth_frames)
+    gray, binp = ctx.gray_threshold(batch)
+    for b in range(len(batch)):
+        og = orc.bgr2gray(batch[b])
+        assert np.array_equal(gray[b], og)
+        for s, ob in enumerate(_oracle_bin(og)):
+            assert np.array_equal(((binp[b] >> s) & 1) * 255, ob)
+    # single-channel input goes through unchanged
+    g2, b2 = ctx.gray_threshold(gray[0])
+    assert np.array_equal(g2[0], gray[0]) and np.array_equal(b2[0], binp[0])
+
+
+def test_gray_threshold_odd_sizes(ctx):
+    rng = np.random.default_rng(5)
+    for (h, w) in [(33, 40), (100, 136), (479, 648), (720, 1280)]:
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        # smooth it a little so the threshold is not trivially all-zero
+        img[:, : w // 2] //= 2
+        gray, binp = ctx.gray_threshold(img)
+        og = orc.bgr2gray(img)
+        assert np.array_equal(gray[0], og), (h, w)
+        for s, ob in enumerate(_oracle_bin(og)):
+            assert np.array_equal(((binp[0] >> s) & 1) * 255, ob), (h, w, s)
+
+
+def _oracle_contours(gray, h, w):
+    minp, maxp = int(0.03 * max(h, w)), int(4.0 * max(h, w))
+    out = set()
+    for s, ob in enumerate(_oracle_bin(gray)):
+        for c in orc.find_contours(ob):
+            if minp <= len(c) <= maxp:
+                out.add((s, int(c[0][1]) * w + int(c[0][0]), len(c)))
+    return out
+
+
+@pytest.mark.parametrize("name", ["pic_1.png", "pic_2.png"])
+def test_contours_match_sequential_border_following(ctx, name):
+    bgr = _data.load_bgr(name)
+    h, w = bgr.shape[:2]
+    ctx.detect(bgr)
+    d = ctx.debug_contours(0, cap=65536)
+    got = set(zip(d["scale"].tolist(), d["start_key"].tolist(), d["length"].tolist()))
+    want = _oracle_contours(orc.bgr2gray(bgr), h, w)
+    assert got == want, f"missing {len(want - got)} extra {len(got - want)}"
+
+
+def _reorder(q):
+    q = q.copy()
+    d1 = q[1] - q[0]
+    d2 = q[2] - q[0]
+    if float(d1[0]) * float(d2[1]) - float(d1[1]) * float(d2[0]) < 0:
+        q[[1, 3]] = q[[3, 1]]
+    return q
+
+
+def _oracle_quads(gray):
+    out = set()
+    for s, ob in enumerate(_oracle_bin(gray)):
+        quads, key, clen = orc.quad_candidates(ob)
+        for q, n in zip(quads, clen):
+            out.add((s, int(n)) + tuple(int(v) for v in _reorder(q).ravel()))
+    return out
+
+
+@pytest.mark.parametrize("name", ["pic_1.png", "pic_2.png"])
+def test_quads_bit_exact(ctx, name):
+    bgr = _data.load_bgr(name)
+    ctx.detect(bgr)
+    d = ctx.debug_quads(0)
+    got = set((int(s), int(n)) + tuple(int(v) for v in c.ravel())
+              for s, n, c in zip(d["scale"], d["contour_len"], d["corners"]))
+    want = _oracle_quads(orc.bgr2gray(bgr))
+    assert got == want, f"missing {sorted(want - got)[:3]} extra {sorted(got - want)[:3]}"
+    # identification of every quad candidate agrees with the oracle
+    gray = orc.bgr2gray(bgr)
+    for c, i, r in zip(d["corners"], d["id"], d["rot"]):
+        ok, oid, orot, _ = orc.identify(gray, c)
+        assert (int(i) >= 0) == ok
+        if ok:
+            assert (int(i), int(r)) == (oid, orot)
+
+
+@pytest.mark.parametrize("name", ["pic_1", "pic_2"])
+def test_detect_reference_goldens(ctx, name):
+    """The reference's own known-answer test (camera_sync/test_aruco.py:203-326)."""
+    bgr = _data.load_bgr(name + ".png")
+    ids, corners, counts, rej, rejc = ctx.detect(bgr)
+    n = int(counts[0])
+    G = _data.goldens()[name]
+    assert sorted(ids[0, :n].tolist()) == list(range(10, 16))
+    for i in range(n):
+        assert np.allclose(corners[0, i], np.array(G[str(int(ids[0, i]))]), atol=1e-3)
+    # and the oracle, same order, tighter
+    oids, ocor, orej = orc.detect(bgr)
+    assert ids[0, :n].tolist() == oids.tolist()
+    assert np.abs(corners[0, :n] - ocor).max() <= 1e-3
+    assert int(rejc[0]) == len(orej)
+    assert np.array_equal(rej[0, :len(orej)], orej)
+
+
+def test_detect_synthetic_vs_oracle(ctx, synth_frames):
+    batch = np.stack(synth_frames)
+    ids, corners, counts, rej, rejc = ctx.detect(batch)
+    worst = 0.0
+    for b in range(len(batch)):
+        oids, ocor, orej = orc.detect(batch[b])
+        n = int(counts[b])
+        assert ids[b, :n].tolist() == oids.tolist()
+        worst = max(worst, float(np.abs(corners[b, :n] - ocor).max()))
+        assert int(rejc[b]) == len(orej)
+        assert np.array_equal(rej[b, :len(orej)], orej)
+    assert worst <= 1e-3, worst
+
+
+def test_pnp_reference_golden_pose(ctx):
+    """Golden corners -> golden pose (camera_sync/test_aruco.py:345-353), atol 1e-4."""
+    G = _data.goldens()
+    K, dist = _data.calibration(G["pic_2_pose"]["camera"])
+    anchors = G["pic_2_pose"]["anchors"]
+    obj = _data.v1_anchor_points(anchors).reshape(1, 16, 3)
+    img = np.array([G["pic_2"][str(i)] for i in anchors], np.float32).reshape(1, 16, 2)
+    rvec, tvec, ok, mae, rmse = ctx.pnp(obj, img, [16], K, dist)
+    assert ok[0] == 1
+    assert np.allclose(rvec[0], G["pic_2_pose"]["rvec"], atol=1e-4)
+    assert np.allclose(tvec[0], G["pic_2_pose"]["tvec"], atol=1e-4)
+    assert mae[0] < 0.6 and rmse[0] < 0.8
+    o_ok, orv, otv = orc.solve_pnp(obj[0], img[0], K, dist)
+    assert np.allclose(rvec[0], orv, rtol=1e-6, atol=1e-9) and np.allclose(tvec[0], otv, rtol=1e-6, atol=1e-9)
+
+
+def test_detect_pnp_fused_reference_pose(ctx):
+    """processAruco on pic_2 (camera_sync/test_aruco.py:329-359) through the fused entry point."""
+    G = _data.goldens()
+    K, dist = _data.calibration(G["pic_2_pose"]["camera"])
+    anchors = G["pic_2_pose"]["anchors"]
+    bgr = _data.load_bgr("pic_2.png")
+    ids, corners, counts, rvec, tvec, ok, mae, rmse = ctx.detect_pnp(bgr, anchors, _data.v1_anchor_points(anchors), K, dist)
+    assert ok[0] == 1
+    assert np.allclose(rvec[0], G["pic_2_pose"]["rvec"], atol=1e-4)
+    assert np.allclose(tvec[0], G["pic_2_pose"]["tvec"], atol=1e-4)
+    assert mae[0] < 0.6 and rmse[0] < 0.8
+
+
+def test_pnp_batch_random_poses_vs_oracle(ctx):
+    from cameracalibration_amd import synth
+    K, dist = _data.calibration("Logitec_robot_1920-1080_10.npz")
+    rng = np.random.default_rng(11)
+    B = 64
+    obj = np.broadcast_to(_data.v1_anchor_points().reshape(1, 16, 3), (B, 16, 3)).copy()
+    img = np.zeros((B, 16, 2), np.float32)
+    for b in range(B):
+        R, t = synth.look_at_pose(rng, (95.0, -135.0))
+        rv = orc.rodrigues_mat2vec(R)
+        img[b] = (orc.project_points(obj[b], rv, t, K, dist) + rng.normal(0, 0.3, (16, 2))).astype(np.float32)
+    npts = np.full(B, 16, np.int32)
+    npts[5] = 8  # ragged: only the first two anchors seen
+    npts[6] = 0  # nothing seen
+    rvec, tvec, ok, mae, rmse = ctx.pnp(obj, img, npts, K, dist)
+    assert ok[6] == 0
+    for b in range(B):
+        if b == 6:
+            continue
+        o_ok, orv, otv = orc.solve_pnp(obj[b, :npts[b]], img[b, :npts[b]], K, dist)
+        assert ok[b] == 1 and o_ok
+        assert np.allclose(rvec[b], orv, rtol=1e-6, atol=1e-8), (b, rvec[b], orv)
+        assert np.allclose(tvec[b], otv, rtol=1e-6, atol=1e-6), (b, tvec[b], otv)
+
+
+def test_ippe_square_vs_oracle(ctx):
+    G = _data.goldens()
+    K, dist = _data.calibration("Logitec_A_1280-720_0.npz")
+    corners = np.array([G["pic_2"][str(i)] for i in (10, 11, 12, 13, 14, 15)], np.float32)
+    rvec, tvec, ok = ctx.ippe_square(corners, 80.0, K, dist)
+    for i in range(len(corners)):
+        o_ok, orv, otv = orc.ippe_square(corners[i], 80.0, K, dist)
+        assert ok[i] == 1 and o_ok
+        assert np.allclose(rvec[i], orv, rtol=1e-6, atol=1e-8)
+        assert np.allclose(tvec[i], otv, rtol=1e-6, atol=1e-6)
+        # the marker must reproject onto its corners
+        h = 40.0
+        sq = np.array([[-h, h, 0], [h, h, 0], [h, -h, 0], [-h, -h, 0]])
+        pr = orc.project_points(sq, rvec[i], tvec[i], K, dist)
+        assert np.abs(pr - corners[i]).max() < 1.5
+
+
+@pytest.mark.parametrize("rational", [False, True])
+def test_calibrate_vs_oracle(ctx, rational):
+    from cameracalibration_amd import synth
+    obj, img, K0, d0 = synth.calib_views(V=24, seed=7, rational=rational)
+    rms, K, dist, rv, tv, iters = ctx.calibrate(obj, img, (1920, 1080), rational=rational)
+    o_rms, oK, odist, orv, otv, oit = orc.calibrate(obj, img, (1920, 1080), rational=rational)
+    assert abs(rms - o_rms) <= 1e-6, (rms, o_rms)
+    assert rms < 0.45
+    assert np.allclose(K, oK, rtol=1e-5)
+    assert abs(K[0, 0] - 1400) < 15 and abs(K[1, 1] - 1400) < 15
