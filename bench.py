@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""bench.py — marker frames/s (detect + anchor PnP) on synthetic 1080p frames.
+
+Workload (BASELINE.json configs[1]): ArUco DICT_4X4_50 detection + anchor
+solvePnP on 4096 synthetic 1920x1080 BGR frames per GPU, inputs resident in HBM
+before the timed region.  One "step" = one pass of the whole hot path
+(gray + 3 adaptive thresholds + contours + quads + identification + sub-pixel
+corners + PnP) over the rank's 4096 frames through the C ABI
+(camsync_detect_pnp_resident).  Multi-GPU: frames shard across ranks, no
+data-path collective (weak scaling); torch.distributed is only the barrier and
+the max-over-ranks of the step time.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALG_BYTES_PER_PX_K1K2 = 8.0   # gray 3r+1w, threshold 1r+3w  (fused kernel k_gray_thresh3)
+ALG_BYTES_PER_PX_K1K3 = 11.0  # + contour extraction 3r
+HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def make_frames(torch, dev, n_frames, H, W, K, pool=32, seed=1234):
+    """n_frames synthetic frames [n,H,W,3] u8 on `dev`: `pool` rendered poses of the v1 sheet,
+    each frame = pose (i % pool) + its own Gaussian noise (sigma 4, seed per frame block)."""
+    from cameracalibration_amd import synth
+    clean = []
+    rng_np = np.random.default_rng(seed)
+    for i in range(pool):
+        R, t = synth.look_at_pose(np.random.default_rng(seed + i), (95.0, -135.0))
+        img = synth.render_sheet(synth.SHEET_V1, K, R, t, H, W, seed=seed + i, ss=2, noise_sigma=0.0, device=dev)
+        clean.append(img[:, :, 0].to(torch.float32))
+    clean = torch.stack(clean)  # [pool,H,W]
+    frames = torch.empty((n_frames, H, W, 3), dtype=torch.uint8, device=dev)
+    g = torch.Generator(device=dev).manual_seed(seed)
+    blk = 64
+    for b0 in range(0, n_frames, blk):
+        nb = min(blk, n_frames - b0)
+        idx = (torch.arange(b0, b0 + nb, device=dev) % pool)
+        noise = torch.randn((nb, H, W, 3), generator=g, device=dev, dtype=torch.float32) * 4.0
+        frames[b0:b0 + nb] = (clean[idx][..., None] + noise).round_().clamp_(0, 255).to(torch.uint8)
+    del rng_np
+    return frames
+
+
+def cpu_baseline(sample_frames, anchors_ids, anchor_obj, K, dist, threads):
+    """Oracle (CPU restatement) detect + PnP on a bounded sample, frame-parallel threads."""
+    from tests import _oracle as orc
+    orc.lib()
+
+    def one(img):
+        ids, cor, _ = orc.detect(img)
+        found = {int(i): c for i, c in zip(ids, cor)}
+        obj, pts = [], []
+        for a, o in zip(anchors_ids, anchor_obj):
+            if a in found:
+                obj.append(o)
+                pts.append(found[a])
+        if obj:
+            orc.solve_pnp(np.concatenate(obj), np.concatenate(pts), K, dist)
+        return len(ids)
+
+    one(sample_frames[0])  # warm
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(threads) as ex:
+        n = list(ex.map(one, list(sample_frames)))
+    dt = time.perf_counter() - t0
+    return len(sample_frames) / dt, n
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--frames", type=int, default=4096, help="frames per GPU per step")
+    ap.add_argument("--chunk", type=int, default=256, help="frames per kernel launch sequence")
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--cpu-sample", type=int, default=48)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--calib-views", type=int, default=2000)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist_mod
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (libcamsync_hip has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist_mod.init_process_group("nccl", device_id=dev)
+
+    from cameracalibration_amd import _hip
+    from tests import _data
+
+    H, W = args.height, args.width
+    K, dist = _data.calibration("Logitec_robot_1920-1080_10.npz")
+    if (H, W) != (1080, 1920):
+        K = K.copy()
+        K[0] *= W / 1920.0
+        K[1] *= H / 1080.0
+    anchors = [10, 11, 14, 15]
+    anchor_obj = _data.v1_anchor_points(anchors)
+
+    frames = make_frames(torch, dev, args.frames, H, W, K, seed=1234 + 100000 * rank)
+    B = args.frames
+    MM = 16
+    d_ids = torch.full((B, MM), -1, dtype=torch.int32, device=dev)
+    d_cor = torch.zeros((B, MM, 4, 2), dtype=torch.float32, device=dev)
+    d_cnt = torch.zeros((B,), dtype=torch.int32, device=dev)
+    d_rv = torch.zeros((B, 3), dtype=torch.float64, device=dev)
+    d_tv = torch.zeros((B, 3), dtype=torch.float64, device=dev)
+    d_ok = torch.zeros((B,), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+
+    ctx = _hip.Context(H, W, max_batch=min(args.chunk, B), device=local_rank)
+
+    def step():
+        ctx.detect_pnp_resident(frames.data_ptr(), B, H, W, 3, anchors, anchor_obj, K, dist, MM,
+                                d_ids.data_ptr(), d_cor.data_ptr(), d_cnt.data_ptr(), d_rv.data_ptr(),
+                                d_tv.data_ptr(), d_ok.data_ptr())
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist_mod.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist_mod.all_reduce(tt, op=dist_mod.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # sanity of the timed work: every frame must have produced its 6 markers and a pose
+    n_ok = int(d_ok.to(torch.int64).sum().item())
+    mean_markers = float(d_cnt.to(torch.float64).mean().item())
+
+    # per-kernel time for the roofline: one more (untimed) pass with the ctx's hipEvent stage timers
+    ctx.enable_timers(True)
+    ctx.reset_timers()
+    step()
+    tm = ctx.timers()
+    ctx.enable_timers(False)
+    ms0, n0 = tm["gray_threshold"]
+    px_per_launch = min(args.chunk, B) * H * W
+    # launches can be short at the tail; use totals: bytes of all launches / total time
+    alg_bytes = ALG_BYTES_PER_PX_K1K2 * B * H * W
+    achieved = alg_bytes / (ms0 * 1e-3) / 1e9 if ms0 > 0 else 0.0
+    stage_ms = {k: round(v[0], 3) for k, v in tm.items()}
+
+    out = None
+    if rank == 0:
+        value = world * B * args.steps / dt
+        out = {
+            "metric": "marker frames/sec (detect+PnP) 1080p",
+            "value": value,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {"workload": f"configs[1]: DICT_4X4_50 detect + anchor PnP, {B} synthetic {W}x{H} BGR frames per GPU, "
+                                   f"6 markers (v1 sheet), 4 anchors, chunk {min(args.chunk, B)}",
+                       "frames_per_gpu": B, "height": H, "width": W, "parallelism": f"frames sharded x{world}"},
+            "roofline": {"bound": "hbm", "kernel": "k_gray_thresh3 (K1+K2 fused)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_px": ALG_BYTES_PER_PX_K1K2, "px_per_launch": px_per_launch,
+                         "avg_launch_ms": ms0 / max(n0, 1),
+                         "pipeline_frac_k1k3": (ALG_BYTES_PER_PX_K1K3 * H * W * value / max(world, 1)) / 1e9 / HBM_PEAK_GBS},
+            "stage_ms_per_step": stage_ms,
+            "check": {"frames_with_pose": n_ok, "mean_markers_per_frame": mean_markers},
+        }
+        if not args.no_cpu and world == 1:
+            threads = max(1, min(16, len(os.sched_getaffinity(0))))
+            sample = frames[:args.cpu_sample].cpu().numpy()
+            fps, _ = cpu_baseline(sample, anchors, anchor_obj, K, dist, threads)
+            out["cpu_baseline"] = {"value": fps, "unit": "frames/s", "cores": threads, "kind": "port",
+                                   "sample": f"first {len(sample)} of the same frames, oracle (CPU restatement, not OpenCV) "
+                                             f"detect+PnP, {threads} frame-parallel threads"}
+        # secondary metric: calibration LM iterations/s (configs[3] on one GPU)
+        try:
+            from cameracalibration_amd import synth
+            obj, img, _, _ = synth.calib_views(V=args.calib_views, seed=42, rational=True)
+            ctx.calibrate(obj[:64], img[:64], (1920, 1080), rational=True, max_iter=2)  # warm
+            t1 = time.perf_counter()
+            rms, _, _, _, _, iters = ctx.calibrate(obj, img, (1920, 1080), rational=True, max_iter=30)
+            t2 = time.perf_counter()
+            out["calib_lm"] = {"views": args.calib_views, "iters": iters, "iters_per_s": iters / (t2 - t1),
+                               "rms_px": rms, "includes": "init (homographies + per-view PnP) + LM"}
+        except Exception as e:  # secondary; never hide the main line
+            out["calib_lm"] = {"error": str(e)}
+        print(json.dumps(out))
+    if world > 1:
+        dist_mod.barrier()
+        dist_mod.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
