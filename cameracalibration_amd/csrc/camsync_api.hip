@@ -24,8 +24,10 @@ struct camsync_ctx {
     std::string err;
 
     // device scratch
-    uint8_t* d_in = nullptr;
+    uint8_t* d_in = nullptr;   // staging for host frames (lazy)
     size_t inBytes = 0;
+    uint8_t* d_bin = nullptr;  // byte-per-pixel threshold images for camsync_gray_threshold (lazy)
+    int planeScales = 0;       // scales the bit-plane buffer is sized for
     DetBuffers buf{};
     uint16_t* d_dict = nullptr;
     float* d_expTab = nullptr;
@@ -93,6 +95,7 @@ DetCfg make_cfg(const camsync_ctx* c, int H, int W) {
     DetCfg g{};
     g.H = H;
     g.W = W;
+    g.WS = (W + 31) / 32;
     g.nScales = (p.adaptiveThreshWinSizeMax - p.adaptiveThreshWinSizeMin) / p.adaptiveThreshWinSizeStep + 1;
     g.nScales = std::min(g.nScales, kMaxScales);
     for (int i = 0; i < g.nScales; i++) {
@@ -157,11 +160,38 @@ struct StageTimer {
     }
 };
 
+int ensure_staging(camsync_ctx* c) {
+    if (c->d_in) return CAMSYNC_OK;
+    c->inBytes = (size_t)c->maxB * c->maxH * c->maxW * 3;
+    HIPCHK(c, dalloc(&c->d_in, c->inBytes));
+    return CAMSYNC_OK;
+}
+
+int ensure_bin(camsync_ctx* c) {
+    if (c->d_bin) return CAMSYNC_OK;
+    HIPCHK(c, dalloc(&c->d_bin, (size_t)c->maxB * c->maxH * c->maxW));
+    return CAMSYNC_OK;
+}
+
+int ensure_planes(camsync_ctx* c, int nScales) {
+    if (nScales <= c->planeScales) return CAMSYNC_OK;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->buf.planes) (void)hipFree(c->buf.planes);
+    c->buf.planes = nullptr;
+    c->planeScales = 0;
+    HIPCHK(c, dalloc(&c->buf.planes, (size_t)c->maxB * nScales * (size_t)c->maxH * ((c->maxW + 31) / 32)));
+    c->planeScales = nScales;
+    return CAMSYNC_OK;
+}
+
 // Enqueue the detection pipeline for one chunk already resident at d_in.
 int enqueue_detect(camsync_ctx* c, const uint8_t* d_in, int B, int H, int W, int C) {
     DetCfg cfg = make_cfg(c, H, W);
+    int rcp = ensure_planes(c, cfg.nScales);
+    if (rcp) return rcp;
     DetBuffers b = c->buf;
     b.in = d_in;
+    b.bin = nullptr;
     HIPCHK(c, hipMemsetAsync(b.counters, 0, sizeof(Counters), c->stream));
     HIPCHK(c, hipMemsetAsync(b.qcount, 0, sizeof(int) * B, c->stream));
     StageTimer t(c);
@@ -298,12 +328,14 @@ int camsync_create(camsync_ctx** out, int device, int max_h, int max_w, int max_
     HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     const size_t px = (size_t)max_h * max_w, B = (size_t)max_batch;
     DetBuffers& b = c->buf;
-    c->inBytes = B * px * 3;
-    HIPCHK(c, dalloc(&c->d_in, c->inBytes));
+    // the host-input staging buffer and the byte-per-pixel threshold image are allocated on first use
     HIPCHK(c, dalloc(&b.gray, B * px));
-    HIPCHK(c, dalloc(&b.bin, B * px));
-    b.candCap = (unsigned)std::min<size_t>(B * (px / 16), 0x7FFFFFFFu);
+    b.bin = nullptr;
+    c->planeScales = 3;
+    HIPCHK(c, dalloc(&b.planes, B * c->planeScales * (size_t)max_h * ((max_w + 31) / 32)));
+    b.candCap = (unsigned)std::min<size_t>(std::max<size_t>(B * (px / 32), 1u << 16), 0x7FFFFFFFu);
     HIPCHK(c, dalloc(&b.cand, b.candCap));
+    HIPCHK(c, dalloc(&b.candLong, b.candCap));
     b.contourCap = (unsigned)std::min<size_t>(B * 4096, 0x7FFFFFFFu);
     HIPCHK(c, dalloc(&b.contours, b.contourCap));
     b.poolCap = (unsigned)std::min<size_t>(B * (size_t)262144, 0x7FFFFFFFu);
@@ -342,7 +374,7 @@ void camsync_destroy(camsync_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DetBuffers& b = c->buf;
-    void* ptrs[] = {c->d_in, b.gray, b.bin, b.cand, b.contours, b.pool, b.quads, b.qcount, b.counters, b.markers,
+    void* ptrs[] = {c->d_in, c->d_bin, b.planes, b.gray, b.cand, b.candLong, b.contours, b.pool, b.quads, b.qcount, b.counters, b.markers,
                     b.outIds, b.outCorners, b.rawCorners, b.outCounts, b.outRejected, b.outRejCounts, c->d_dict, c->d_expTab,
                     c->d_obj, c->d_img, c->d_npts, c->d_K, c->d_dist, c->d_rvec, c->d_tvec, c->d_mae, c->d_rmse, c->d_ok,
                     c->d_anchorIds, c->d_anchorObj, c->d_calObj, c->d_calImg, c->cal.intr, c->cal.ext, c->cal.intrTrial,
@@ -399,14 +431,23 @@ int camsync_gray_threshold(camsync_ctx* c, const uint8_t* frames, int on_device,
         const uint8_t* src = frames + (size_t)b0 * px * C;
         const uint8_t* d_in = src;
         if (!on_device) {
+            int rcs = ensure_staging(c);
+            if (rcs) return rcs;
             HIPCHK(c, hipMemcpyAsync(c->d_in, src, (size_t)nb * px * C, hipMemcpyHostToDevice, c->stream));
             d_in = c->d_in;
         } else if (((uintptr_t)src) % 8) {
             return fail(c, CAMSYNC_E_ARG, "device frames must be 8-byte aligned");
         }
         DetCfg cfg = make_cfg(c, H, W);
+        rc = ensure_planes(c, cfg.nScales);
+        if (rc) return rc;
+        if (bin_out) {
+            rc = ensure_bin(c);
+            if (rc) return rc;
+        }
         DetBuffers b = c->buf;
         b.in = d_in;
+        b.bin = bin_out ? c->d_bin : nullptr;
         StageTimer t(c);
         launch_gray_thresh(cfg, b, nb, C, c->stream);
         t.mark(0);
@@ -451,6 +492,8 @@ static int detect_impl(camsync_ctx* c, const uint8_t* frames, int on_device, int
         const uint8_t* src = frames + (size_t)b0 * px * C;
         const uint8_t* d_in = src;
         if (!on_device) {
+            int rcs = ensure_staging(c);
+            if (rcs) return rcs;
             HIPCHK(c, hipMemcpyAsync(c->d_in, src, (size_t)nb * px * C, hipMemcpyHostToDevice, c->stream));
             d_in = c->d_in;
         } else if (((uintptr_t)src) % 8) {
@@ -583,7 +626,7 @@ int camsync_debug_counts(camsync_ctx* c, int frame, int32_t out[8]) {
     int q = 0;
     if (frame >= 0 && frame < c->lastB) HIPCHK(c, hipMemcpy(&q, c->buf.qcount + frame, sizeof q, hipMemcpyDeviceToHost));
     out[0] = (int32_t)h.nCand; out[1] = (int32_t)h.nContours; out[2] = (int32_t)h.nPool; out[3] = (int32_t)h.nMarkers;
-    out[4] = (int32_t)h.overflow; out[5] = q; out[6] = c->lastB; out[7] = 0;
+    out[4] = (int32_t)h.overflow; out[5] = q; out[6] = (int32_t)h.nLong; out[7] = (int32_t)h.pad[0];
     return CAMSYNC_OK;
 }
 

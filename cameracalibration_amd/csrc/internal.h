@@ -18,6 +18,7 @@ constexpr int kMaxAnchors = 64;
 // to kernels by value.
 struct DetCfg {
     int H, W;
+    int WS;                  // 32-bit words per bit-plane row = ceil(W/32)
     int nScales;
     int radius[kMaxScales];  // adaptive threshold half windows
     int idelta;              // floor(adaptiveThreshConstant)
@@ -72,14 +73,17 @@ struct Counters {
     unsigned int nPool;
     unsigned int nMarkers;
     unsigned int overflow;  // bit0 cand, bit1 contours, bit2 pool, bit3 quads, bit4 sel, bit5 markers
-    unsigned int pad[3];
+    unsigned int nLong;     // candidates handed from the short-trace pass to the long-trace pass
+    unsigned int pad[2];
 };
 
 struct DetBuffers {
     const uint8_t* in;   // [B,H,W,C]
     uint8_t* gray;       // [B,H,W]
-    uint8_t* bin;        // [B,H,W] packed scale bits
+    uint8_t* bin;        // [B,H,W] packed scale bits (only when a caller asks for the threshold images), else null
+    uint32_t* planes;    // [B,nScales,H,WS] one bit per pixel (bit x&31 of word x>>5), image frame zeroed
     uint64_t* cand;
+    uint64_t* candLong;  // same capacity as cand
     unsigned int candCap;
     ContourRec* contours;
     unsigned int contourCap;

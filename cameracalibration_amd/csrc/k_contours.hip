@@ -9,238 +9,430 @@
 //     component (search for the first neighbour begins west, clockwise);
 //   * a hole border starts at the pixel left of the raster-first pixel of the
 //     hole (4-connected zero component), search begins east.
-// So: (1) a stencil pass lists every pixel that can be such a start
-// (outer: p=1, W=NW=N=NE=0; hole: p=0, W=1, N=1), (2) one lane per candidate
-// follows the border exactly like OpenCV's icvFetchContour and drops the
-// candidate as soon as it meets a crack with a smaller raster key (it is then
-// not the canonical start), (3) survivors whose length passes the perimeter
-// filter are traced once more to store their points.
-// The traces only read the image, so they are independent.
+// The threshold images arrive as bit planes (one bit per pixel, image frame
+// already zeroed), so:
+//   (1) k_contour_starts finds every pixel that can be such a start with a few
+//       word-wide bit operations per 32 pixels (outer: p=1, W=NW=N=NE=0;
+//       hole: p=0, W=1, N=1), drops isolated pixels, and drops starts whose
+//       horizontal run touches the row above further right (the component /
+//       hole then begins earlier): that removes the staircase peaks of slanted
+//       edges without tracing them.  Starts are staged in LDS and appended to
+//       the global list with one atomic per flush.
+//   (2) k_trace_short follows each candidate's border exactly like OpenCV's
+//       icvFetchContour for a few dozen steps, one lane per candidate, in
+//       lock-step with a second tracer walking the same border the other way
+//       round (the vertical mirror image of the algorithm).  A candidate is
+//       dropped as soon as either tracer meets a crack with a smaller raster
+//       key (it is not the canonical start) or the border closes below the
+//       minimum perimeter.  Noise specks and false starts end here.
+//   (3) Candidates still alive are compacted into a second list and
+//       k_trace_long finishes them (all lanes of a wave now hold long borders,
+//       so the wave is not idling on one lane); survivors within the perimeter
+//       bounds get a slot in the point pool;
+//   (4) k_trace_store follows the survivors once more to store their points.
+// The traces only read the image, so they are independent of each other.
 #include "internal.h"
 
 namespace camsync {
 
 namespace {
 
-__device__ __forceinline__ uint32_t ld_row(const uint8_t* __restrict__ img, int H, int W, int y, int xd) {
-    // dword xd (pixels 4xd..4xd+3) of row y, with the 1-px image frame zeroed
-    if (y <= 0 || y >= H - 1 || xd < 0 || 4 * xd >= W) return 0u;
-    uint32_t v = *reinterpret_cast<const uint32_t*>(img + (size_t)y * W + 4 * xd);
-    if (xd == 0) v &= 0xFFFFFF00u;
-    if (4 * xd + 3 == W - 1) v &= 0x00FFFFFFu;
-    return v;
+// fill `seed` along runs of `run` towards lower bit positions (Kogge-Stone)
+__device__ __forceinline__ uint32_t fill_down(uint32_t seed, uint32_t run) {
+    uint32_t f = seed & run, m = run;
+    f |= (f >> 1) & m; m &= m >> 1;
+    f |= (f >> 2) & m; m &= m >> 2;
+    f |= (f >> 4) & m; m &= m >> 4;
+    f |= (f >> 8) & m; m &= m >> 8;
+    f |= (f >> 16) & m;
+    return f;
 }
 
-// Stencil pass.  One thread per 4 pixels; all scales at once (SWAR on the
-// packed scale bits).  W % 4 == 0.
-__global__ __launch_bounds__(256) void k_contour_starts(const uint8_t* __restrict__ bin, DetCfg cfg, int B,
+constexpr int kStage = 2048;  // starts staged per workgroup before a flush
+
+// One thread per 32-pixel word of one scale plane.
+__global__ __launch_bounds__(256) void k_contour_starts(const uint32_t* __restrict__ planes, DetCfg cfg, int B,
                                                         uint64_t* __restrict__ cand, unsigned int candCap,
                                                         Counters* __restrict__ ctr) {
-    const int H = cfg.H, W = cfg.W, W4 = W / 4;
-    const size_t total = (size_t)B * H * W4;
-    const uint32_t scaleMask = ((1u << cfg.nScales) - 1u) * 0x01010101u;
+    __shared__ unsigned int s_cnt, s_base;
+    __shared__ uint64_t s_list[kStage];
+    const int H = cfg.H, WS = cfg.WS, S = cfg.nScales, W = cfg.W;
+    const size_t total = (size_t)B * S * H * WS;
     const bool dropIsolated = cfg.minPerim > 1;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
     for (size_t base = (size_t)blockIdx.x * blockDim.x; base < total; base += (size_t)gridDim.x * blockDim.x) {
-        size_t i = base + threadIdx.x;
+        const size_t i = base + threadIdx.x;
         uint32_t outer = 0, hole = 0;
-        int f = 0, y = 0, xd = 0;
+        int f = 0, sc = 0, y = 0, xw = 0;
         if (i < total) {
-            xd = (int)(i % W4);
-            y = (int)((i / W4) % H);
-            f = (int)(i / ((size_t)W4 * H));
-            const uint8_t* img = bin + (size_t)f * H * W;
-            uint32_t c = ld_row(img, H, W, y, xd);
-            uint32_t cl = ld_row(img, H, W, y, xd - 1), cr = ld_row(img, H, W, y, xd + 1);
-            uint32_t n = ld_row(img, H, W, y - 1, xd);
-            uint32_t nl = ld_row(img, H, W, y - 1, xd - 1), nr = ld_row(img, H, W, y - 1, xd + 1);
-            uint32_t w = (c << 8) | (cl >> 24);
-            uint32_t nw = (n << 8) | (nl >> 24);
-            uint32_t ne = (n >> 8) | (nr << 24);
-            outer = c & ~w & ~nw & ~n & ~ne & scaleMask;
-            hole = ~c & w & n & scaleMask;
-            if (dropIsolated && outer) {
-                uint32_t s = ld_row(img, H, W, y + 1, xd);
-                uint32_t sl = ld_row(img, H, W, y + 1, xd - 1), sr = ld_row(img, H, W, y + 1, xd + 1);
-                uint32_t e = (c >> 8) | (cr << 24);
-                uint32_t sw = (s << 8) | (sl >> 24);
-                uint32_t se = (s >> 8) | (sr << 24);
-                outer &= (e | sw | s | se);  // w,nw,n,ne are already zero where outer is set
+            xw = (int)(i % WS);
+            y = (int)((i / WS) % H);
+            const size_t fs = i / ((size_t)WS * H);
+            sc = (int)(fs % S);
+            f = (int)(fs / S);
+            if (y >= 1 && y <= H - 2) {
+                const uint32_t* row = planes + (fs * H + y) * (size_t)WS;
+                const uint32_t c = row[xw];
+                const uint32_t n = row[xw - WS];
+                if (c | n) {  // nothing can start in an all-zero word under an all-zero word
+                    const uint32_t cl = xw > 0 ? row[xw - 1] : 0u, cr = xw + 1 < WS ? row[xw + 1] : 0u;
+                    const uint32_t nl = xw > 0 ? row[xw - 1 - WS] : 0u, nr = xw + 1 < WS ? row[xw + 1 - WS] : 0u;
+                    const uint32_t w = (c << 1) | (cl >> 31);
+                    const uint32_t nw = (n << 1) | (nl >> 31);
+                    const uint32_t ne = (n >> 1) | (nr << 31);
+                    const uint32_t above = n | nw | ne;  // some foreground 8-adjacent in the row above
+                    outer = c & ~w & ~above;
+                    hole = ~c & w & n;
+                    if ((xw + 1) * 32 > W) {  // pixels beyond the image width are padding, never starts
+                        const uint32_t valid = (1u << (W - xw * 32)) - 1u;
+                        hole &= valid;
+                    }
+                    if (outer) {
+                        // the run that starts here must not touch the row above anywhere
+                        outer &= ~fill_down(above, c);
+                        // a run that leaves the word through bit 31 is followed into the next words
+                        if ((c >> 31) && outer) {
+                            const uint32_t top = 1u << (32 - __clz(~c));  // lowest bit of the run ending at bit 31
+                            if (outer & top) {
+                                bool bad = false;
+                                for (int k = xw + 1; k < WS; k++) {
+                                    const uint32_t ck = row[k];
+                                    if (!(ck & 1u)) break;
+                                    const uint32_t nk = row[k - WS];
+                                    const uint32_t nkl = row[k - 1 - WS], nkr = k + 1 < WS ? row[k + 1 - WS] : 0u;
+                                    const uint32_t ab = nk | (nk << 1) | (nkl >> 31) | (nk >> 1) | (nkr << 31);
+                                    const int t = __ffs(~ck) - 1;  // run covers bits [0,t), t = -1 means all 32
+                                    const uint32_t rmask = (t < 0) ? 0xFFFFFFFFu : ((1u << t) - 1u);
+                                    if (ab & rmask) { bad = true; break; }
+                                    if (t >= 0) break;
+                                }
+                                if (bad) outer &= ~top;
+                            }
+                        }
+                        if (dropIsolated && outer) {
+                            const uint32_t s = row[xw + WS];
+                            const uint32_t sl = xw > 0 ? row[xw - 1 + WS] : 0u, sr = xw + 1 < WS ? row[xw + 1 + WS] : 0u;
+                            const uint32_t e = (c >> 1) | (cr << 31);
+                            const uint32_t sw = (s << 1) | (sl >> 31);
+                            const uint32_t se = (s >> 1) | (sr << 31);
+                            outer &= (e | sw | s | se);
+                        }
+                    }
+                    if (hole) {
+                        // the zero run that starts here must have foreground directly above all along
+                        hole &= ~fill_down(~n, ~c);
+                        if (!(c >> 31) && hole) {
+                            const uint32_t top = 1u << (32 - __clz(c));  // lowest bit of the zero run ending at bit 31
+                            if (hole & top) {
+                                bool bad = false;
+                                for (int k = xw + 1; k < WS; k++) {
+                                    const uint32_t zk = ~row[k];
+                                    if (!(zk & 1u)) break;
+                                    const uint32_t nz = ~row[k - WS];
+                                    const int t = __ffs(~zk) - 1;
+                                    const uint32_t rmask = (t < 0) ? 0xFFFFFFFFu : ((1u << t) - 1u);
+                                    if (nz & rmask) { bad = true; break; }
+                                    if (t >= 0) break;
+                                }
+                                if (bad) hole &= ~top;
+                            }
+                        }
+                    }
+                }
             }
         }
+        // stage in LDS; flush when the staging area could overflow in the next round
         const int cnt = __popc(outer) + __popc(hole);
-        // wave-aggregated append
-        int incl = cnt;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            int t = __shfl_up(incl, d, 64);
-            if ((int)(threadIdx.x & 63) >= d) incl += t;
+        unsigned int o = 0;
+        if (cnt) o = atomicAdd(&s_cnt, (unsigned int)cnt);
+        const bool fits = o + (unsigned int)cnt <= (unsigned int)kStage;
+        if (cnt && fits) {
+            const uint32_t rowPos = (uint32_t)y * W + 32u * xw;
+            uint32_t m = outer;
+            while (m) {
+                const int bit = __ffs(m) - 1;
+                m &= m - 1;
+                s_list[o++] = pack_cand(f, 0, sc, rowPos + bit);
+            }
+            m = hole;
+            while (m) {
+                const int bit = __ffs(m) - 1;
+                m &= m - 1;
+                s_list[o++] = pack_cand(f, 1, sc, rowPos + bit - 1);  // start pixel is left of the first hole pixel
+            }
         }
-        const int waveTotal = __shfl(incl, 63, 64);
-        unsigned int wbase = 0;
-        if (waveTotal) {
-            if ((threadIdx.x & 63) == 63) wbase = atomicAdd(&ctr->nCand, (unsigned int)waveTotal);
-            wbase = __shfl(wbase, 63, 64);
-            unsigned int o = wbase + (unsigned int)(incl - cnt);
-            if (wbase + (unsigned int)waveTotal > candCap) {
-                if ((threadIdx.x & 63) == 63) atomicOr(&ctr->overflow, 1u);
-            } else {
-                const uint32_t rowPos = (uint32_t)y * W + 4u * xd;
-                uint32_t m = outer;
-                while (m) {
-                    int bit = __ffs(m) - 1;
-                    m &= m - 1;
-                    cand[o++] = pack_cand(f, 0, bit & 7, rowPos + (bit >> 3));
-                }
-                m = hole;
-                while (m) {
-                    int bit = __ffs(m) - 1;
-                    m &= m - 1;
-                    // start pixel is the one left of the first hole pixel
-                    cand[o++] = pack_cand(f, 1, bit & 7, rowPos + (bit >> 3) - 1);
+        __syncthreads();
+        const unsigned int staged = s_cnt;
+        const bool last = base + (size_t)gridDim.x * blockDim.x >= total;
+        if (staged > (unsigned int)kStage) {
+            // this round did not fit: flush what was staged before it, then write this round's starts directly
+            // (s_cnt counts reservations, the entries beyond kStage were not stored)
+            // entries stored: all reservations with o + cnt <= kStage
+            // simplest exact handling: every thread that did not fit appends globally on its own
+            if (cnt && !fits) {
+                unsigned int g = atomicAdd(&ctr->nCand, (unsigned int)cnt);
+                if (g + cnt > candCap) {
+                    atomicOr(&ctr->overflow, 1u);
+                } else {
+                    const uint32_t rowPos = (uint32_t)y * W + 32u * xw;
+                    uint32_t m = outer;
+                    while (m) {
+                        const int bit = __ffs(m) - 1;
+                        m &= m - 1;
+                        cand[g++] = pack_cand(f, 0, sc, rowPos + bit);
+                    }
+                    m = hole;
+                    while (m) {
+                        const int bit = __ffs(m) - 1;
+                        m &= m - 1;
+                        cand[g++] = pack_cand(f, 1, sc, rowPos + bit - 1);
+                    }
                 }
             }
+            // threads that fitted stored below kStage, but the slots of the ones that did not are holes:
+            // mark holes invalid so the flush can skip them
+            if (cnt && !fits) {
+                for (unsigned int k = o; k < o + (unsigned int)cnt && k < (unsigned int)kStage; k++) s_list[k] = ~0ull;
+            }
+            __syncthreads();
+        }
+        const unsigned int nflush = staged < (unsigned int)kStage ? staged : (unsigned int)kStage;
+        // a later round adds at most 256*32 starts; flush early enough that the common case never overflows
+        if (nflush && (last || staged > (unsigned int)(kStage - 512))) {
+            if (threadIdx.x == 0) s_base = atomicAdd(&ctr->nCand, nflush);
+            __syncthreads();
+            const unsigned int gb = s_base;
+            if (gb + nflush > candCap) {
+                if (threadIdx.x == 0) atomicOr(&ctr->overflow, 1u);
+            } else {
+                for (unsigned int k = threadIdx.x; k < nflush; k += blockDim.x) cand[gb + k] = s_list[k];
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) s_cnt = 0;
+            __syncthreads();
         }
     }
 }
 
-__device__ __forceinline__ uint32_t nb_mask(const uint8_t* __restrict__ img, int H, int W, int x, int y, int sc) {
-    // bit d = neighbour of (x,y) in direction d is foreground.
-    // directions: 0=E 1=NE 2=N 3=NW 4=W 5=SW 6=S 7=SE.  (x,y) is interior.
-    const uint8_t* r0 = img + (size_t)(y - 1) * W + x;
-    const uint8_t* r1 = r0 + W;
-    const uint8_t* r2 = r1 + W;
-    uint32_t nw = r0[-1], n = r0[0], ne = r0[1], w = r1[-1], e = r1[1], sw = r2[-1], s = r2[0], se = r2[1];
-    const bool top = (y - 1) <= 0, bot = (y + 1) >= H - 1, lef = (x - 1) <= 0, rig = (x + 1) >= W - 1;
-    uint32_t m = 0;
-    m |= (!rig && ((e >> sc) & 1u)) ? 1u : 0u;
-    m |= (!rig && !top && ((ne >> sc) & 1u)) ? 2u : 0u;
-    m |= (!top && ((n >> sc) & 1u)) ? 4u : 0u;
-    m |= (!lef && !top && ((nw >> sc) & 1u)) ? 8u : 0u;
-    m |= (!lef && ((w >> sc) & 1u)) ? 16u : 0u;
-    m |= (!lef && !bot && ((sw >> sc) & 1u)) ? 32u : 0u;
-    m |= (!bot && ((s >> sc) & 1u)) ? 64u : 0u;
-    m |= (!rig && !bot && ((se >> sc) & 1u)) ? 128u : 0u;
-    return m;
+// 3-bit fields (x-1, x, x+1) of rows y-1, y, y+1 -> neighbour mask, bit d = neighbour in direction d.
+// directions: 0=E 1=NE 2=N 3=NW 4=W 5=SW 6=S 7=SE.  (x,y) is an interior pixel; the planes have a zero frame.
+__device__ __forceinline__ uint32_t nb_mask(const uint32_t* __restrict__ plane, int WS, int x, int y) {
+    const int wi = (x - 1) >> 5, sh = (x - 1) & 31;
+    const uint32_t* r1 = plane + (size_t)y * WS + wi;
+    const uint32_t* r0 = r1 - WS;
+    const uint32_t* r2 = r1 + WS;
+    uint64_t a = r0[0], b = r1[0], c = r2[0];
+    if (sh > 29) {
+        a |= (uint64_t)r0[1] << 32;
+        b |= (uint64_t)r1[1] << 32;
+        c |= (uint64_t)r2[1] << 32;
+    }
+    const uint32_t t = (uint32_t)(a >> sh) & 7u, m = (uint32_t)(b >> sh) & 7u, u = (uint32_t)(c >> sh) & 7u;
+    return ((m >> 2) & 1u) | (((t >> 2) & 1u) << 1) | (((t >> 1) & 1u) << 2) | ((t & 1u) << 3) | ((m & 1u) << 4) |
+           ((u & 1u) << 5) | (((u >> 1) & 1u) << 6) | (((u >> 2) & 1u) << 7);
+}
+
+// the same mask in the direction numbering of the vertically mirrored image (d -> (8 - d) & 7)
+__device__ __forceinline__ uint32_t flip_mask(uint32_t m) {
+    return (m & 0x11u) | ((m & 0x02u) << 6) | ((m & 0x80u) >> 6) | ((m & 0x04u) << 4) | ((m & 0x40u) >> 4) |
+           ((m & 0x08u) << 2) | ((m & 0x20u) >> 2);
 }
 
 __device__ __forceinline__ int dir_dx(int d) { return (d == 0 || d == 1 || d == 7) ? 1 : (d >= 3 && d <= 5) ? -1 : 0; }
 __device__ __forceinline__ int dir_dy(int d) { return (d >= 1 && d <= 3) ? -1 : (d >= 5 && d <= 7) ? 1 : 0; }
 
-// Follows one border like OpenCV's icvFetchContour.  STORE = false: count the
-// points, abort when the start turns out not to be canonical or the border is
-// longer than maxLen.  STORE = true: write the points.  Returns the number of
-// points, or 0 when aborted.
-template <bool STORE>
-__device__ int follow_border(const uint8_t* __restrict__ img, int H, int W, int sc, int x0, int y0, bool isHole,
-                             int maxLen, uint32_t* __restrict__ out) {
-    const int startKey = y0 * W + x0;
-    int s_end = isHole ? 0 : 4;
-    int s = s_end;
-    uint32_t m = nb_mask(img, H, W, x0, y0, sc);
-    bool found = false;
-    for (int k = 0; k < 8; k++) {
-        s = (s - 1) & 7;
-        if (s == s_end) break;
-        if ((m >> s) & 1u) { found = true; break; }
+// One border follower with OpenCV's icvFetchContour stepping rule.  FLIP runs the rule on the vertically
+// mirrored image, which walks the same border in the opposite sense; it is only used to look for an earlier
+// start, never to produce points.
+template <bool FLIP>
+struct Tracer {
+    int x0, y0, x1, y1, cx, cy, s;
+    uint32_t m;
+
+    __device__ __forceinline__ uint32_t mask(const uint32_t* plane, int WS, int x, int y) const {
+        const uint32_t v = nb_mask(plane, WS, x, y);
+        return FLIP ? flip_mask(v) : v;
     }
-    if (!found) {  // single pixel
-        if (STORE) out[0] = (uint32_t)x0 | ((uint32_t)y0 << 16);
-        return 1;
-    }
-    const int x1 = x0 + dir_dx(s), y1 = y0 + dir_dy(s);
-    int cx = x0, cy = y0, count = 0;
-    for (;;) {
-        s_end = s;
-        // first foreground neighbour counter-clockwise after s_end
-        uint32_t rot = ((m >> (s_end + 1)) | (m << (7 - s_end))) & 0xFFu;  // bit j <-> direction s_end+1+j
-        int k = __ffs(rot);                                                // 1..8 (m has at least the arrival neighbour)
-        if (k == 0) return 0;                                              // cannot happen on a consistent image
-        s = (s_end + k) & 7;
-        if (!STORE) {
-            const int key = cy * W + cx;
-            if (isHole) {
-                if (s_end + k >= 9 && key < startKey) return 0;  // an east crack of this border lies before the start
-            } else {
-                if (key < startKey) return 0;
-            }
+    __device__ __forceinline__ int dy(int d) const { return FLIP ? -dir_dy(d) : dir_dy(d); }
+
+    // returns false for a single-pixel border
+    __device__ __forceinline__ bool init(const uint32_t* plane, int WS, int x, int y, bool isHole) {
+        x0 = cx = x;
+        y0 = cy = y;
+        const int s_end = isHole ? 0 : 4;
+        s = s_end;
+        m = mask(plane, WS, x, y);
+        bool found = false;
+        for (int k = 0; k < 8; k++) {
+            s = (s - 1) & 7;
+            if (s == s_end) break;
+            if ((m >> s) & 1u) { found = true; break; }
         }
-        if (STORE) out[count] = (uint32_t)cx | ((uint32_t)cy << 16);
-        count++;
-        const int nx = cx + dir_dx(s), ny = cy + dir_dy(s);
-        if (nx == x0 && ny == y0 && cx == x1 && cy == y1) break;
-        if (count >= maxLen) return STORE ? count : 0;
+        x1 = x0 + dir_dx(s);
+        y1 = y0 + dy(s);
+        return found;
+    }
+
+    // One step.  Reports the pixel being left (px,py) and whether its east crack is on this border.
+    // Returns true when the border closed with this step.
+    __device__ __forceinline__ bool step(const uint32_t* plane, int WS, int& px, int& py, bool& passedEast) {
+        const int s_end = s;
+        const uint32_t rot = ((m >> (s_end + 1)) | (m << (7 - s_end))) & 0xFFu;  // bit j <-> direction s_end+1+j
+        const int k = __ffs(rot);  // 1..8: m always holds the neighbour we came from
+        s = (s_end + k) & 7;
+        passedEast = s_end + k >= 9;
+        px = cx;
+        py = cy;
+        const int nx = cx + dir_dx(s), ny = cy + dy(s);
+        const bool closed = (nx == x0 && ny == y0 && cx == x1 && cy == y1);
         cx = nx;
         cy = ny;
         s = (s + 4) & 7;
-        m = nb_mask(img, H, W, cx, cy, sc);
+        if (!closed) m = mask(plane, WS, cx, cy);
+        return closed;
     }
-    return count;
-}
+};
 
-__global__ __launch_bounds__(256) void k_trace_count(const uint8_t* __restrict__ bin, DetCfg cfg,
-                                                     const uint64_t* __restrict__ cand, ContourRec* __restrict__ contours,
-                                                     unsigned int contourCap, unsigned int poolCap, Counters* __restrict__ ctr) {
-    const unsigned int n = min(ctr->nCand, 0xFFFFFFFFu);
-    const int H = cfg.H, W = cfg.W;
-    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const uint64_t c = cand[i];
-        const uint32_t pos = (uint32_t)(c & 0xFFFFFFFFull);
-        const int sc = (int)((c >> 36) & 7u);
-        const bool hole = (c >> 39) & 1u;
-        const uint32_t f = (uint32_t)(c >> 40);
-        const int x0 = pos % W, y0 = pos / W;
-        const uint8_t* img = bin + (size_t)f * H * W;
-        // one more point than allowed is enough to know the border is too long
-        const int len = follow_border<false>(img, H, W, sc, x0, y0, hole, cfg.maxPerim + 1, nullptr);
-        if (len >= cfg.minPerim && len <= cfg.maxPerim && len > 0) {
-            const unsigned int off = atomicAdd(&ctr->nPool, (unsigned int)len);
-            if (off + (unsigned int)len > poolCap) {
-                atomicOr(&ctr->overflow, 4u);
-                continue;
-            }
-            const unsigned int slot = atomicAdd(&ctr->nContours, 1u);
-            if (slot >= contourCap) {
-                atomicOr(&ctr->overflow, 2u);
-                continue;
-            }
-            ContourRec r;
-            r.frame = f;
-            r.pos = pos;
-            r.len = (uint32_t)len;
-            r.off = off;
-            r.scale = (uint16_t)sc;
-            r.hole = hole ? 1 : 0;
-            r.scanKey = pos + (hole ? 1u : 0u);
-            contours[slot] = r;
+// Follow the candidate's border for at most `budget` forward steps, in lock-step with the mirrored tracer.
+// Returns  >0  the border closed with that many points (it is a canonical start),
+//           0  the candidate is not a canonical start (dropped),
+//          -1  the budget ran out first (undecided).
+__device__ int probe_border(const uint32_t* __restrict__ plane, int WS, int W, int x0, int y0, bool isHole, int budget) {
+    const int startKey = y0 * W + x0;
+    Tracer<false> fw;
+    Tracer<true> bw;
+    if (!fw.init(plane, WS, x0, y0, isHole)) return 1;
+    bool bwActive = bw.init(plane, WS, x0, y0, isHole);
+    int count = 0;
+    for (;;) {
+        int px, py;
+        bool east;
+        const bool closed = fw.step(plane, WS, px, py, east);
+        if ((isHole ? east : true) && py * W + px < startKey) return 0;
+        count++;
+        if (closed) return count;
+        if (count >= budget) return -1;
+        if (bwActive) {
+            const bool bclosed = bw.step(plane, WS, px, py, east);
+            if ((isHole ? east : true) && py * W + px < startKey) return 0;
+            if (bclosed) bwActive = false;
         }
     }
 }
 
-__global__ __launch_bounds__(64) void k_trace_store(const uint8_t* __restrict__ bin, DetCfg cfg,
+__device__ __forceinline__ void emit_contour(uint64_t c, int len, ContourRec* __restrict__ contours,
+                                             unsigned int contourCap, unsigned int poolCap, Counters* __restrict__ ctr) {
+    const uint32_t pos = (uint32_t)(c & 0xFFFFFFFFull);
+    const bool hole = (c >> 39) & 1u;
+    const unsigned int off = atomicAdd(&ctr->nPool, (unsigned int)len);
+    if (off + (unsigned int)len > poolCap) {
+        atomicOr(&ctr->overflow, 4u);
+        return;
+    }
+    const unsigned int slot = atomicAdd(&ctr->nContours, 1u);
+    if (slot >= contourCap) {
+        atomicOr(&ctr->overflow, 2u);
+        return;
+    }
+    ContourRec r;
+    r.frame = (uint32_t)(c >> 40);
+    r.pos = pos;
+    r.len = (uint32_t)len;
+    r.off = off;
+    r.scale = (uint16_t)((c >> 36) & 7u);
+    r.hole = hole ? 1 : 0;
+    r.scanKey = pos + (hole ? 1u : 0u);
+    contours[slot] = r;
+}
+
+constexpr int kShortBudget = 48;
+
+template <bool LONG>
+__global__ __launch_bounds__(256) void k_trace(const uint32_t* __restrict__ planes, DetCfg cfg,
+                                               const uint64_t* __restrict__ cand, unsigned int candCap,
+                                               uint64_t* __restrict__ candLong, ContourRec* __restrict__ contours,
+                                               unsigned int contourCap, unsigned int poolCap, Counters* __restrict__ ctr) {
+    const unsigned int n = min(LONG ? ctr->nLong : ctr->nCand, candCap);
+    const int H = cfg.H, W = cfg.W, WS = cfg.WS, S = cfg.nScales;
+    const unsigned int stride = gridDim.x * blockDim.x;
+    // all lanes of a wave run the same number of rounds so the wave-wide append below is convergent
+    for (unsigned int i0 = blockIdx.x * blockDim.x; i0 < n; i0 += stride) {
+        const unsigned int i = i0 + threadIdx.x;
+        uint64_t c = 0;
+        int res = 0;
+        if (i < n) c = cand[i];
+        if (i < n && c != ~0ull) {  // ~0 marks a staging slot that was never filled
+            const uint32_t pos = (uint32_t)(c & 0xFFFFFFFFull);
+            const int sc = (int)((c >> 36) & 7u);
+            const bool hole = (c >> 39) & 1u;
+            const uint32_t f = (uint32_t)(c >> 40);
+            const uint32_t* plane = planes + ((size_t)f * S + sc) * (size_t)H * WS;
+            // one more point than allowed is enough to know the border is too long
+            res = probe_border(plane, WS, W, pos % W, pos / W, hole, LONG ? cfg.maxPerim + 1 : kShortBudget);
+        }
+        if (res >= cfg.minPerim && res <= cfg.maxPerim) emit_contour(c, res, contours, contourCap, poolCap, ctr);
+        if (!LONG) {
+            const bool undecided = res == -1;
+            const unsigned long long bal = __ballot(undecided);
+            if (bal) {
+                const int lane = threadIdx.x & 63;
+                unsigned int wbase = 0;
+                if (lane == 0) wbase = atomicAdd(&ctr->nLong, (unsigned int)__popcll(bal));
+                wbase = __shfl(wbase, 0, 64);
+                if (undecided) {
+                    const unsigned int o = wbase + (unsigned int)__popcll(bal & ((1ull << lane) - 1ull));
+                    if (o < candCap) candLong[o] = c;
+                    else atomicOr(&ctr->overflow, 1u);
+                }
+            }
+        }
+    }
+}
+
+__device__ void store_border(const uint32_t* __restrict__ plane, int WS, int x0, int y0, bool isHole, int len,
+                             uint32_t* __restrict__ out) {
+    Tracer<false> fw;
+    if (!fw.init(plane, WS, x0, y0, isHole)) {
+        out[0] = (uint32_t)x0 | ((uint32_t)y0 << 16);
+        return;
+    }
+    for (int count = 0; count < len; count++) {
+        int px, py;
+        bool east;
+        const bool closed = fw.step(plane, WS, px, py, east);
+        out[count] = (uint32_t)px | ((uint32_t)py << 16);
+        if (closed) break;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_trace_store(const uint32_t* __restrict__ planes, DetCfg cfg,
                                                     const ContourRec* __restrict__ contours, unsigned int contourCap,
                                                     uint32_t* __restrict__ pool, const Counters* __restrict__ ctr) {
     const unsigned int n = min(ctr->nContours, contourCap);
-    const int H = cfg.H, W = cfg.W;
+    const int H = cfg.H, W = cfg.W, WS = cfg.WS, S = cfg.nScales;
     for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const ContourRec r = contours[i];
-        const uint8_t* img = bin + (size_t)r.frame * H * W;
-        follow_border<true>(img, H, W, r.scale, r.pos % W, r.pos / W, r.hole != 0, (int)r.len, pool + r.off);
+        const uint32_t* plane = planes + ((size_t)r.frame * S + r.scale) * (size_t)H * WS;
+        store_border(plane, WS, r.pos % W, r.pos / W, r.hole != 0, (int)r.len, pool + r.off);
     }
 }
 
 }  // namespace
 
 void launch_contour_starts(const DetCfg& c, const DetBuffers& b, int B, hipStream_t st) {
-    size_t total = (size_t)B * c.H * (c.W / 4);
-    size_t nblk = (total + 255) / 256;
-    unsigned blocks = (unsigned)(nblk < (size_t)(256 * 16) ? nblk : (size_t)(256 * 16));
-    hipLaunchKernelGGL(k_contour_starts, dim3(blocks), dim3(256), 0, st, b.bin, c, B, b.cand, b.candCap, b.counters);
+    const size_t total = (size_t)B * c.nScales * c.H * c.WS;
+    const size_t nblk = (total + 255) / 256;
+    const unsigned blocks = (unsigned)(nblk < (size_t)(256 * 16) ? nblk : (size_t)(256 * 16));
+    hipLaunchKernelGGL(k_contour_starts, dim3(blocks), dim3(256), 0, st, b.planes, c, B, b.cand, b.candCap, b.counters);
 }
 
 void launch_trace(const DetCfg& c, const DetBuffers& b, hipStream_t st) {
-    hipLaunchKernelGGL(k_trace_count, dim3(256 * 8), dim3(256), 0, st, b.bin, c, b.cand, b.contours, b.contourCap,
-                       b.poolCap, b.counters);
-    hipLaunchKernelGGL(k_trace_store, dim3(256 * 8), dim3(64), 0, st, b.bin, c, b.contours, b.contourCap, b.pool,
+    hipLaunchKernelGGL(k_trace<false>, dim3(256 * 8), dim3(256), 0, st, b.planes, c, b.cand, b.candCap, b.candLong,
+                       b.contours, b.contourCap, b.poolCap, b.counters);
+    hipLaunchKernelGGL(k_trace<true>, dim3(256 * 8), dim3(64), 0, st, b.planes, c, b.candLong, b.candCap, b.candLong,
+                       b.contours, b.contourCap, b.poolCap, b.counters);
+    hipLaunchKernelGGL(k_trace_store, dim3(256 * 8), dim3(64), 0, st, b.planes, c, b.contours, b.contourCap, b.pool,
                        b.counters);
 }
 

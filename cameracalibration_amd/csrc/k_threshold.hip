@@ -104,7 +104,7 @@ __device__ __forceinline__ void hsum8(const uint16_t* xb, int base, uint32_t out
 
 template <int R0, int R1, int R2>
 __global__ __launch_bounds__(TPB) void k_gray_thresh3(const uint8_t* __restrict__ in, int C, uint8_t* __restrict__ gray,
-                                                      uint8_t* __restrict__ bin, int H, int W, int bandH, int idelta) {
+                                                      uint8_t* __restrict__ bin, uint32_t* __restrict__ planes, int WS, int H, int W, int bandH, int idelta) {
     constexpr int RMAX = R2;
     constexpr int RING = 2 * RMAX + 2;
     static_assert(R0 <= R1 && R1 <= R2 && R2 <= HALO - 1, "radii must be sorted and fit the halo");
@@ -190,28 +190,50 @@ __global__ __launch_bounds__(TPB) void k_gray_thresh3(const uint8_t* __restrict_
             hsum8<R2>(&xbuf[buf][2][0], PX * tid, s2);
             constexpr int K0 = (2 * R0 + 1) * (2 * R0 + 1), K1 = (2 * R1 + 1) * (2 * R1 + 1), K2 = (2 * R2 + 1) * (2 * R2 + 1);
             uint32_t ob[8];
+            uint32_t pm0 = 0, pm1 = 0, pm2 = 0;  // one byte per scale, bit i = pixel xbase+i
 #pragma unroll
             for (int i = 0; i < 8; i++) {
                 int t2 = 2 * ((int)c[i] + idelta) - 1;
-                uint32_t m = 0;
-                m |= ((int)(2 * s0[i]) >= t2 * K0) ? 1u : 0u;
-                m |= ((int)(2 * s1[i]) >= t2 * K1) ? 2u : 0u;
-                m |= ((int)(2 * s2[i]) >= t2 * K2) ? 4u : 0u;
-                ob[i] = m;
+                const uint32_t b0 = ((int)(2 * s0[i]) >= t2 * K0) ? 1u : 0u;
+                const uint32_t b1 = ((int)(2 * s1[i]) >= t2 * K1) ? 1u : 0u;
+                const uint32_t b2 = ((int)(2 * s2[i]) >= t2 * K2) ? 1u : 0u;
+                ob[i] = b0 | (b1 << 1) | (b2 << 2);
+                pm0 |= b0 << i;
+                pm1 |= b1 << i;
+                pm2 |= b2 << i;
             }
-            uint2 o;
-            o.x = ob[0] | (ob[1] << 8) | (ob[2] << 16) | (ob[3] << 24);
-            o.y = ob[4] | (ob[5] << 8) | (ob[6] << 16) | (ob[7] << 24);
             const size_t off = frameOff + (size_t)y * W + xbase;
             if (fullOut) {
-                *reinterpret_cast<uint2*>(bin + off) = o;
+                if (bin) {
+                    uint2 o;
+                    o.x = ob[0] | (ob[1] << 8) | (ob[2] << 16) | (ob[3] << 24);
+                    o.y = ob[4] | (ob[5] << 8) | (ob[6] << 16) | (ob[7] << 24);
+                    *reinterpret_cast<uint2*>(bin + off) = o;
+                }
                 if (gray) *reinterpret_cast<uint2*>(gray + off) = cen;
             } else {
                 for (int i = 0; i < 8; i++)
                     if (xbase + i < W) {
-                        bin[off + i] = (uint8_t)ob[i];
+                        if (bin) bin[off + i] = (uint8_t)ob[i];
                         if (gray) gray[off + i] = (uint8_t)c[i];
                     }
+            }
+            // bit planes with the 1-pixel image frame zeroed (what findContours works on)
+            uint32_t keep = 0xFFu;
+            if (y == 0 || y == H - 1) keep = 0;
+            if (xbase == 0) keep &= 0xFEu;
+            if (xbase + 7 >= W - 1) keep &= ~(1u << ((W - 1) - xbase)) & ((W - xbase) >= 8 ? 0xFFu : ((1u << (W - xbase)) - 1u));
+            const size_t rowBytes = (size_t)WS * 4;
+            uint8_t* pl = reinterpret_cast<uint8_t*>(planes) + ((size_t)f * 3 * H + y) * rowBytes + (xbase >> 3);
+            const size_t planeBytes = (size_t)H * rowBytes;
+            pl[0] = (uint8_t)(pm0 & keep);
+            pl[planeBytes] = (uint8_t)(pm1 & keep);
+            pl[2 * planeBytes] = (uint8_t)(pm2 & keep);
+            if (xbase + 8 >= W) {  // last byte of the row: clear the row padding
+                for (int pb = (xbase >> 3) + 1; pb < (int)rowBytes; pb++) {
+                    uint8_t* q = reinterpret_cast<uint8_t*>(planes) + ((size_t)f * 3 * H + y) * rowBytes + pb;
+                    q[0] = 0; q[planeBytes] = 0; q[2 * planeBytes] = 0;
+                }
             }
         }
         buf ^= 1;
@@ -227,30 +249,48 @@ __global__ void k_gray_generic(const uint8_t* __restrict__ in, int C, uint8_t* _
     else gray[i] = in[i];
 }
 
-__global__ void k_thresh_generic(const uint8_t* __restrict__ gray, uint8_t* __restrict__ bin, DetCfg cfg, int B) {
-    const int H = cfg.H, W = cfg.W;
+// one thread per 8 pixels (one plane byte per scale)
+__global__ void k_thresh_generic(const uint8_t* __restrict__ gray, uint8_t* __restrict__ bin, uint32_t* __restrict__ planes,
+                                 DetCfg cfg, int B) {
+    const int H = cfg.H, W = cfg.W, W8 = W / 8;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (size_t)B * H * W) return;
-    int x = (int)(i % W);
-    int y = (int)((i / W) % H);
-    const uint8_t* g = gray + (i / ((size_t)W * H)) * (size_t)W * H;
-    int src = g[(size_t)y * W + x];
-    uint32_t m = 0;
-    for (int s = 0; s < cfg.nScales; s++) {
-        int r = cfg.radius[s];
-        int sum = 0;
-        for (int dy = -r; dy <= r; dy++) {
-            int yy = min(max(y + dy, 0), H - 1);
-            for (int dx = -r; dx <= r; dx++) {
-                int xx = min(max(x + dx, 0), W - 1);
-                sum += g[(size_t)yy * W + xx];
+    if (i >= (size_t)B * H * W8) return;
+    const int xb = (int)(i % W8);
+    const int y = (int)((i / W8) % H);
+    const size_t f = i / ((size_t)W8 * H);
+    const uint8_t* g = gray + f * (size_t)W * H;
+    const size_t rowBytes = (size_t)cfg.WS * 4, planeBytes = (size_t)H * rowBytes;
+    uint32_t pm[kMaxScales];
+    for (int s = 0; s < cfg.nScales; s++) pm[s] = 0;
+    for (int k = 0; k < 8; k++) {
+        const int x = xb * 8 + k;
+        const int src = g[(size_t)y * W + x];
+        uint32_t m = 0;
+        for (int s = 0; s < cfg.nScales; s++) {
+            const int r = cfg.radius[s];
+            int sum = 0;
+            for (int dy = -r; dy <= r; dy++) {
+                const int yy = min(max(y + dy, 0), H - 1);
+                for (int dx = -r; dx <= r; dx++) {
+                    const int xx = min(max(x + dx, 0), W - 1);
+                    sum += g[(size_t)yy * W + xx];
+                }
+            }
+            const int k2 = (2 * r + 1) * (2 * r + 1);
+            const long long t2 = 2 * (src + cfg.idelta) - 1;
+            if (2LL * sum >= t2 * k2) {
+                m |= 1u << s;
+                if (y > 0 && y < H - 1 && x > 0 && x < W - 1) pm[s] |= 1u << k;
             }
         }
-        int k2 = (2 * r + 1) * (2 * r + 1);
-        long long t2 = 2 * (src + cfg.idelta) - 1;
-        if (2LL * sum >= t2 * k2) m |= 1u << s;
+        if (bin) bin[f * (size_t)W * H + (size_t)y * W + x] = (uint8_t)m;
     }
-    bin[i] = (uint8_t)m;
+    uint8_t* pl = reinterpret_cast<uint8_t*>(planes) + (f * cfg.nScales * H + y) * rowBytes + xb;
+    for (int s = 0; s < cfg.nScales; s++) {
+        pl[s * planeBytes] = (uint8_t)pm[s];
+        if (xb == W8 - 1)
+            for (int pb = 1; xb + pb < (int)rowBytes; pb++) pl[s * planeBytes + pb] = 0;
+    }
 }
 
 }  // namespace
@@ -265,12 +305,14 @@ void launch_gray_thresh(const DetCfg& c, const DetBuffers& b, int B, int C, hipS
         int bandH = (c.H + bands - 1) / bands;
         bands = (c.H + bandH - 1) / bandH;
         dim3 grid(chunks, bands, B);
-        hipLaunchKernelGGL((k_gray_thresh3<1, 6, 11>), grid, dim3(TPB), 0, st, b.in, C, b.gray, b.bin, c.H, c.W, bandH, c.idelta);
+        hipLaunchKernelGGL((k_gray_thresh3<1, 6, 11>), grid, dim3(TPB), 0, st, b.in, C, b.gray, b.bin, b.planes, c.WS, c.H, c.W, bandH, c.idelta);
     } else {
         size_t total = (size_t)B * c.H * c.W;
         unsigned blocks = (unsigned)((total + 255) / 256);
         hipLaunchKernelGGL(k_gray_generic, dim3(blocks), dim3(256), 0, st, b.in, C, b.gray, c.H, c.W, total);
-        hipLaunchKernelGGL(k_thresh_generic, dim3(blocks), dim3(256), 0, st, b.gray, b.bin, c, B);
+        size_t total8 = total / 8;
+        unsigned blocks8 = (unsigned)((total8 + 255) / 256);
+        hipLaunchKernelGGL(k_thresh_generic, dim3(blocks8), dim3(256), 0, st, b.gray, b.bin, b.planes, c, B);
     }
 }
 
