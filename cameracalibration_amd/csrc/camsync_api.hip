@@ -179,7 +179,7 @@ int ensure_planes(camsync_ctx* c, int nScales) {
     if (c->buf.planes) (void)hipFree(c->buf.planes);
     c->buf.planes = nullptr;
     c->planeScales = 0;
-    HIPCHK(c, dalloc(&c->buf.planes, (size_t)c->maxB * nScales * (size_t)c->maxH * ((c->maxW + 31) / 32)));
+    HIPCHK(c, dalloc(&c->buf.planes, (size_t)c->maxB * nScales * plane_words(c->maxH, (c->maxW + 31) / 32)));
     c->planeScales = nScales;
     return CAMSYNC_OK;
 }
@@ -332,7 +332,7 @@ int camsync_create(camsync_ctx** out, int device, int max_h, int max_w, int max_
     HIPCHK(c, dalloc(&b.gray, B * px));
     b.bin = nullptr;
     c->planeScales = 3;
-    HIPCHK(c, dalloc(&b.planes, B * c->planeScales * (size_t)max_h * ((max_w + 31) / 32)));
+    HIPCHK(c, dalloc(&b.planes, B * c->planeScales * plane_words(max_h, (max_w + 31) / 32)));
     b.candCap = (unsigned)std::min<size_t>(std::max<size_t>(B * (px / 32), 1u << 16), 0x7FFFFFFFu);
     HIPCHK(c, dalloc(&b.cand, b.candCap));
     HIPCHK(c, dalloc(&b.candLong, b.candCap));
@@ -626,7 +626,7 @@ int camsync_debug_counts(camsync_ctx* c, int frame, int32_t out[8]) {
     int q = 0;
     if (frame >= 0 && frame < c->lastB) HIPCHK(c, hipMemcpy(&q, c->buf.qcount + frame, sizeof q, hipMemcpyDeviceToHost));
     out[0] = (int32_t)h.nCand; out[1] = (int32_t)h.nContours; out[2] = (int32_t)h.nPool; out[3] = (int32_t)h.nMarkers;
-    out[4] = (int32_t)h.overflow; out[5] = q; out[6] = (int32_t)h.nLong; out[7] = (int32_t)h.pad[0];
+    out[4] = (int32_t)h.overflow; out[5] = q; out[6] = (int32_t)h.nLong; out[7] = (int32_t)h.qDecide;
     return CAMSYNC_OK;
 }
 

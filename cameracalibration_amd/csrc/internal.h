@@ -38,6 +38,15 @@ struct DetCfg {
     int dictN;
 };
 
+// Bit planes are block-linear: a plane is a grid of WS x HB blocks, each block = 32 rows x 32 pixels =
+// 32 words = one 128-byte line (word r of a block holds row r, bit i = pixel i).  A border follower then
+// touches one or two lines per neighbourhood instead of three rows 1024 pixels long.
+__host__ __device__ inline int plane_hb(int H) { return (H + 31) >> 5; }
+__host__ __device__ inline size_t plane_words(int H, int WS) { return (size_t)plane_hb(H) * WS * 32; }
+__host__ __device__ inline size_t plane_word_index(int WS, int xw, int y) {
+    return ((size_t)(y >> 5) * WS + xw) * 32 + (y & 31);
+}
+
 // 64-bit contour-start candidate: frame<<40 | hole<<39 | scale<<36 | pos(y*W+x)
 __host__ __device__ inline uint64_t pack_cand(uint32_t frame, uint32_t hole, uint32_t scale, uint32_t pos) {
     return ((uint64_t)frame << 40) | ((uint64_t)hole << 39) | ((uint64_t)scale << 36) | (uint64_t)pos;
@@ -74,7 +83,8 @@ struct Counters {
     unsigned int nMarkers;
     unsigned int overflow;  // bit0 cand, bit1 contours, bit2 pool, bit3 quads, bit4 sel, bit5 markers
     unsigned int nLong;     // candidates handed from the short-trace pass to the long-trace pass
-    unsigned int pad[2];
+    unsigned int qDecide;   // work-queue heads of the long-border kernels (lanes fetch their next border here)
+    unsigned int qStore;
 };
 
 struct DetBuffers {

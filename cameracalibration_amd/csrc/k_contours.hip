@@ -9,8 +9,8 @@
 //     component (search for the first neighbour begins west, clockwise);
 //   * a hole border starts at the pixel left of the raster-first pixel of the
 //     hole (4-connected zero component), search begins east.
-// The threshold images arrive as bit planes (one bit per pixel, image frame
-// already zeroed), so:
+// The threshold images arrive as block-linear bit planes (internal.h: one bit
+// per pixel, 32x32-pixel blocks of one cache line, image frame zeroed), so:
 //   (1) k_contour_starts finds every pixel that can be such a start with a few
 //       word-wide bit operations per 32 pixels (outer: p=1, W=NW=N=NE=0;
 //       hole: p=0, W=1, N=1), drops isolated pixels, and drops starts whose
@@ -25,11 +25,13 @@
 //       dropped as soon as either tracer meets a crack with a smaller raster
 //       key (it is not the canonical start) or the border closes below the
 //       minimum perimeter.  Noise specks and false starts end here.
-//   (3) Candidates still alive are compacted into a second list and
-//       k_trace_long finishes them (all lanes of a wave now hold long borders,
-//       so the wave is not idling on one lane); survivors within the perimeter
-//       bounds get a slot in the point pool;
-//   (4) k_trace_store follows the survivors once more to store their points.
+//   (3) Candidates still alive go to a work queue.  k_trace_tile<false> is a
+//       persistent kernel whose lanes each follow one long border inside a
+//       private LDS window of the plane and fetch the next border from the
+//       queue when done; borders within the perimeter bounds get a slot in the
+//       point pool.
+//   (4) k_trace_tile<true> follows the accepted borders once more the same way
+//       to store their points.
 // The traces only read the image, so they are independent of each other.
 #include "internal.h"
 
@@ -50,14 +52,21 @@ __device__ __forceinline__ uint32_t fill_down(uint32_t seed, uint32_t run) {
 
 constexpr int kStage = 2048;  // starts staged per workgroup before a flush
 
-// One thread per 32-pixel word of one scale plane.
+// word (xw, y) of a block-linear plane, zero outside the plane
+__device__ __forceinline__ uint32_t pw(const uint32_t* __restrict__ plane, int WS, int H, int xw, int y) {
+    if (xw < 0 || xw >= WS || y < 0 || y >= H) return 0u;
+    return plane[plane_word_index(WS, xw, y)];
+}
+
+// One thread per word, in memory order (a wave reads two whole cache lines of the centre row set).
 __global__ __launch_bounds__(256) void k_contour_starts(const uint32_t* __restrict__ planes, DetCfg cfg, int B,
                                                         uint64_t* __restrict__ cand, unsigned int candCap,
                                                         Counters* __restrict__ ctr) {
     __shared__ unsigned int s_cnt, s_base;
     __shared__ uint64_t s_list[kStage];
     const int H = cfg.H, WS = cfg.WS, S = cfg.nScales, W = cfg.W;
-    const size_t total = (size_t)B * S * H * WS;
+    const size_t perPlane = plane_words(H, WS);
+    const size_t total = (size_t)B * S * perPlane;
     const bool dropIsolated = cfg.minPerim > 1;
     if (threadIdx.x == 0) s_cnt = 0;
     __syncthreads();
@@ -66,18 +75,20 @@ __global__ __launch_bounds__(256) void k_contour_starts(const uint32_t* __restri
         uint32_t outer = 0, hole = 0;
         int f = 0, sc = 0, y = 0, xw = 0;
         if (i < total) {
-            xw = (int)(i % WS);
-            y = (int)((i / WS) % H);
-            const size_t fs = i / ((size_t)WS * H);
+            const size_t fs = i / perPlane;
+            const size_t wi = i - fs * perPlane;
+            const int blk = (int)(wi >> 5);
+            xw = blk % WS;
+            y = (blk / WS) * 32 + (int)(wi & 31);
             sc = (int)(fs % S);
             f = (int)(fs / S);
             if (y >= 1 && y <= H - 2) {
-                const uint32_t* row = planes + (fs * H + y) * (size_t)WS;
-                const uint32_t c = row[xw];
-                const uint32_t n = row[xw - WS];
+                const uint32_t* plane = planes + fs * perPlane;
+                const uint32_t c = plane[wi];
+                const uint32_t n = pw(plane, WS, H, xw, y - 1);
                 if (c | n) {  // nothing can start in an all-zero word under an all-zero word
-                    const uint32_t cl = xw > 0 ? row[xw - 1] : 0u, cr = xw + 1 < WS ? row[xw + 1] : 0u;
-                    const uint32_t nl = xw > 0 ? row[xw - 1 - WS] : 0u, nr = xw + 1 < WS ? row[xw + 1 - WS] : 0u;
+                    const uint32_t cl = pw(plane, WS, H, xw - 1, y), cr = pw(plane, WS, H, xw + 1, y);
+                    const uint32_t nl = pw(plane, WS, H, xw - 1, y - 1), nr = pw(plane, WS, H, xw + 1, y - 1);
                     const uint32_t w = (c << 1) | (cl >> 31);
                     const uint32_t nw = (n << 1) | (nl >> 31);
                     const uint32_t ne = (n >> 1) | (nr << 31);
@@ -97,10 +108,10 @@ __global__ __launch_bounds__(256) void k_contour_starts(const uint32_t* __restri
                             if (outer & top) {
                                 bool bad = false;
                                 for (int k = xw + 1; k < WS; k++) {
-                                    const uint32_t ck = row[k];
+                                    const uint32_t ck = pw(plane, WS, H, k, y);
                                     if (!(ck & 1u)) break;
-                                    const uint32_t nk = row[k - WS];
-                                    const uint32_t nkl = row[k - 1 - WS], nkr = k + 1 < WS ? row[k + 1 - WS] : 0u;
+                                    const uint32_t nk = pw(plane, WS, H, k, y - 1);
+                                    const uint32_t nkl = pw(plane, WS, H, k - 1, y - 1), nkr = pw(plane, WS, H, k + 1, y - 1);
                                     const uint32_t ab = nk | (nk << 1) | (nkl >> 31) | (nk >> 1) | (nkr << 31);
                                     const int t = __ffs(~ck) - 1;  // run covers bits [0,t), t = -1 means all 32
                                     const uint32_t rmask = (t < 0) ? 0xFFFFFFFFu : ((1u << t) - 1u);
@@ -111,8 +122,8 @@ __global__ __launch_bounds__(256) void k_contour_starts(const uint32_t* __restri
                             }
                         }
                         if (dropIsolated && outer) {
-                            const uint32_t s = row[xw + WS];
-                            const uint32_t sl = xw > 0 ? row[xw - 1 + WS] : 0u, sr = xw + 1 < WS ? row[xw + 1 + WS] : 0u;
+                            const uint32_t s = pw(plane, WS, H, xw, y + 1);
+                            const uint32_t sl = pw(plane, WS, H, xw - 1, y + 1), sr = pw(plane, WS, H, xw + 1, y + 1);
                             const uint32_t e = (c >> 1) | (cr << 31);
                             const uint32_t sw = (s << 1) | (sl >> 31);
                             const uint32_t se = (s >> 1) | (sr << 31);
@@ -127,9 +138,9 @@ __global__ __launch_bounds__(256) void k_contour_starts(const uint32_t* __restri
                             if (hole & top) {
                                 bool bad = false;
                                 for (int k = xw + 1; k < WS; k++) {
-                                    const uint32_t zk = ~row[k];
+                                    const uint32_t zk = ~pw(plane, WS, H, k, y);
                                     if (!(zk & 1u)) break;
-                                    const uint32_t nz = ~row[k - WS];
+                                    const uint32_t nz = ~pw(plane, WS, H, k, y - 1);
                                     const int t = __ffs(~zk) - 1;
                                     const uint32_t rmask = (t < 0) ? 0xFFFFFFFFu : ((1u << t) - 1u);
                                     if (nz & rmask) { bad = true; break; }
@@ -147,8 +158,8 @@ __global__ __launch_bounds__(256) void k_contour_starts(const uint32_t* __restri
         unsigned int o = 0;
         if (cnt) o = atomicAdd(&s_cnt, (unsigned int)cnt);
         const bool fits = o + (unsigned int)cnt <= (unsigned int)kStage;
+        const uint32_t rowPos = (uint32_t)y * W + 32u * xw;
         if (cnt && fits) {
-            const uint32_t rowPos = (uint32_t)y * W + 32u * xw;
             uint32_t m = outer;
             while (m) {
                 const int bit = __ffs(m) - 1;
@@ -166,16 +177,13 @@ __global__ __launch_bounds__(256) void k_contour_starts(const uint32_t* __restri
         const unsigned int staged = s_cnt;
         const bool last = base + (size_t)gridDim.x * blockDim.x >= total;
         if (staged > (unsigned int)kStage) {
-            // this round did not fit: flush what was staged before it, then write this round's starts directly
-            // (s_cnt counts reservations, the entries beyond kStage were not stored)
-            // entries stored: all reservations with o + cnt <= kStage
-            // simplest exact handling: every thread that did not fit appends globally on its own
+            // this round did not fit entirely: the threads left out append on their own, and the staging
+            // slots they had reserved (below kStage) are marked empty (~0) so the readers skip them
             if (cnt && !fits) {
                 unsigned int g = atomicAdd(&ctr->nCand, (unsigned int)cnt);
                 if (g + cnt > candCap) {
                     atomicOr(&ctr->overflow, 1u);
                 } else {
-                    const uint32_t rowPos = (uint32_t)y * W + 32u * xw;
                     uint32_t m = outer;
                     while (m) {
                         const int bit = __ffs(m) - 1;
@@ -189,10 +197,6 @@ __global__ __launch_bounds__(256) void k_contour_starts(const uint32_t* __restri
                         cand[g++] = pack_cand(f, 1, sc, rowPos + bit - 1);
                     }
                 }
-            }
-            // threads that fitted stored below kStage, but the slots of the ones that did not are holes:
-            // mark holes invalid so the flush can skip them
-            if (cnt && !fits) {
                 for (unsigned int k = o; k < o + (unsigned int)cnt && k < (unsigned int)kStage; k++) s_list[k] = ~0ull;
             }
             __syncthreads();
@@ -216,21 +220,23 @@ __global__ __launch_bounds__(256) void k_contour_starts(const uint32_t* __restri
 }
 
 // 3-bit fields (x-1, x, x+1) of rows y-1, y, y+1 -> neighbour mask, bit d = neighbour in direction d.
-// directions: 0=E 1=NE 2=N 3=NW 4=W 5=SW 6=S 7=SE.  (x,y) is an interior pixel; the planes have a zero frame.
-__device__ __forceinline__ uint32_t nb_mask(const uint32_t* __restrict__ plane, int WS, int x, int y) {
-    const int wi = (x - 1) >> 5, sh = (x - 1) & 31;
-    const uint32_t* r1 = plane + (size_t)y * WS + wi;
-    const uint32_t* r0 = r1 - WS;
-    const uint32_t* r2 = r1 + WS;
-    uint64_t a = r0[0], b = r1[0], c = r2[0];
-    if (sh > 29) {
-        a |= (uint64_t)r0[1] << 32;
-        b |= (uint64_t)r1[1] << 32;
-        c |= (uint64_t)r2[1] << 32;
-    }
-    const uint32_t t = (uint32_t)(a >> sh) & 7u, m = (uint32_t)(b >> sh) & 7u, u = (uint32_t)(c >> sh) & 7u;
+// directions: 0=E 1=NE 2=N 3=NW 4=W 5=SW 6=S 7=SE.
+__device__ __forceinline__ uint32_t pack_mask(uint32_t t, uint32_t m, uint32_t u) {
     return ((m >> 2) & 1u) | (((t >> 2) & 1u) << 1) | (((t >> 1) & 1u) << 2) | ((t & 1u) << 3) | ((m & 1u) << 4) |
            ((u & 1u) << 5) | (((u >> 1) & 1u) << 6) | (((u >> 2) & 1u) << 7);
+}
+
+// (x,y) is an interior pixel; the planes have a zero frame.
+__device__ __forceinline__ uint32_t nb_mask(const uint32_t* __restrict__ plane, int WS, int x, int y) {
+    const int wi = (x - 1) >> 5, sh = (x - 1) & 31;
+    const size_t i0 = plane_word_index(WS, wi, y - 1), i1 = plane_word_index(WS, wi, y), i2 = plane_word_index(WS, wi, y + 1);
+    uint64_t a = plane[i0], b = plane[i1], c = plane[i2];
+    if (sh > 29) {  // the field straddles two words: same row of the next block
+        a |= (uint64_t)plane[i0 + 32] << 32;
+        b |= (uint64_t)plane[i1 + 32] << 32;
+        c |= (uint64_t)plane[i2 + 32] << 32;
+    }
+    return pack_mask((uint32_t)(a >> sh) & 7u, (uint32_t)(b >> sh) & 7u, (uint32_t)(c >> sh) & 7u);
 }
 
 // the same mask in the direction numbering of the vertically mirrored image (d -> (8 - d) & 7)
@@ -348,13 +354,13 @@ __device__ __forceinline__ void emit_contour(uint64_t c, int len, ContourRec* __
 
 constexpr int kShortBudget = 48;
 
-template <bool LONG>
-__global__ __launch_bounds__(256) void k_trace(const uint32_t* __restrict__ planes, DetCfg cfg,
-                                               const uint64_t* __restrict__ cand, unsigned int candCap,
-                                               uint64_t* __restrict__ candLong, ContourRec* __restrict__ contours,
-                                               unsigned int contourCap, unsigned int poolCap, Counters* __restrict__ ctr) {
-    const unsigned int n = min(LONG ? ctr->nLong : ctr->nCand, candCap);
+__global__ __launch_bounds__(256) void k_trace_short(const uint32_t* __restrict__ planes, DetCfg cfg,
+                                                     const uint64_t* __restrict__ cand, unsigned int candCap,
+                                                     uint64_t* __restrict__ candLong, ContourRec* __restrict__ contours,
+                                                     unsigned int contourCap, unsigned int poolCap, Counters* __restrict__ ctr) {
+    const unsigned int n = min(ctr->nCand, candCap);
     const int H = cfg.H, W = cfg.W, WS = cfg.WS, S = cfg.nScales;
+    const size_t perPlane = plane_words(H, WS);
     const unsigned int stride = gridDim.x * blockDim.x;
     // all lanes of a wave run the same number of rounds so the wave-wide append below is convergent
     for (unsigned int i0 = blockIdx.x * blockDim.x; i0 < n; i0 += stride) {
@@ -367,73 +373,224 @@ __global__ __launch_bounds__(256) void k_trace(const uint32_t* __restrict__ plan
             const int sc = (int)((c >> 36) & 7u);
             const bool hole = (c >> 39) & 1u;
             const uint32_t f = (uint32_t)(c >> 40);
-            const uint32_t* plane = planes + ((size_t)f * S + sc) * (size_t)H * WS;
-            // one more point than allowed is enough to know the border is too long
-            res = probe_border(plane, WS, W, pos % W, pos / W, hole, LONG ? cfg.maxPerim + 1 : kShortBudget);
+            const uint32_t* plane = planes + ((size_t)f * S + sc) * perPlane;
+            res = probe_border(plane, WS, W, pos % W, pos / W, hole, kShortBudget);
         }
         if (res >= cfg.minPerim && res <= cfg.maxPerim) emit_contour(c, res, contours, contourCap, poolCap, ctr);
-        if (!LONG) {
-            const bool undecided = res == -1;
-            const unsigned long long bal = __ballot(undecided);
-            if (bal) {
-                const int lane = threadIdx.x & 63;
-                unsigned int wbase = 0;
-                if (lane == 0) wbase = atomicAdd(&ctr->nLong, (unsigned int)__popcll(bal));
-                wbase = __shfl(wbase, 0, 64);
-                if (undecided) {
-                    const unsigned int o = wbase + (unsigned int)__popcll(bal & ((1ull << lane) - 1ull));
-                    if (o < candCap) candLong[o] = c;
-                    else atomicOr(&ctr->overflow, 1u);
-                }
+        const bool undecided = res == -1;
+        const unsigned long long bal = __ballot(undecided);
+        if (bal) {
+            const int lane = threadIdx.x & 63;
+            unsigned int wbase = 0;
+            if (lane == 0) wbase = atomicAdd(&ctr->nLong, (unsigned int)__popcll(bal));
+            wbase = __shfl(wbase, 0, 64);
+            if (undecided) {
+                const unsigned int o = wbase + (unsigned int)__popcll(bal & ((1ull << lane) - 1ull));
+                if (o < candCap) candLong[o] = c;
+                else atomicOr(&ctr->overflow, 1u);
             }
         }
     }
 }
 
-__device__ void store_border(const uint32_t* __restrict__ plane, int WS, int x0, int y0, bool isHole, int len,
-                             uint32_t* __restrict__ out) {
-    Tracer<false> fw;
-    if (!fw.init(plane, WS, x0, y0, isHole)) {
-        out[0] = (uint32_t)x0 | ((uint32_t)y0 << 16);
-        return;
-    }
-    for (int count = 0; count < len; count++) {
-        int px, py;
-        bool east;
-        const bool closed = fw.step(plane, WS, px, py, east);
-        out[count] = (uint32_t)px | ((uint32_t)py << 16);
-        if (closed) break;
-    }
-}
+// ---- long borders -------------------------------------------------------------------------------
+// Every lane follows one border inside a private LDS window of its bit plane: 2 x 2 half-blocks
+// (32 pixels x 16 rows, 64 bytes each) = 64 columns x 32 rows, addressed toroidally (row y & 31,
+// word (x >> 5) & 1), so shifting the window by one half-block only loads the half-blocks that are new.
+// A step then costs three LDS reads instead of dependent trips to L2/HBM, and the global traffic is whole
+// 64-byte pieces that are fully used.  When any lane of the wave is about to leave its window every lane
+// re-centres (lanes whose window does not move load nothing), which keeps the wave convergent.
+// Lanes that finish fetch their next border from a queue, so a wave stays busy until the queue is empty.
+struct TileWin {
+    int gx, gy;  // window origin in half-block units: columns [32 gx, 32 gx + 64), rows [16 gy, 16 gy + 32)
+    bool valid;
 
-__global__ __launch_bounds__(64) void k_trace_store(const uint32_t* __restrict__ planes, DetCfg cfg,
-                                                    const ContourRec* __restrict__ contours, unsigned int contourCap,
-                                                    uint32_t* __restrict__ pool, const Counters* __restrict__ ctr) {
-    const unsigned int n = min(ctr->nContours, contourCap);
+    __device__ __forceinline__ bool covers(int x, int y) const {
+        return valid && ((x - 1) >> 5) >= gx && ((x + 1) >> 5) <= gx + 1 && ((y - 1) >> 4) >= gy && ((y + 1) >> 4) <= gy + 1;
+    }
+    __device__ __forceinline__ void recentre(const uint32_t* __restrict__ plane, int WS, int H, int x, int y,
+                                             uint32_t* __restrict__ tile, int lane) {
+        const int ngx = (x - 16) >> 5, ngy = (y - 8) >> 4;
+        const int hbRows = plane_hb(H) * 2;
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                const int hx = ngx + i, hy = ngy + j;
+                const bool have = valid && hx >= gx && hx <= gx + 1 && hy >= gy && hy <= gy + 1;
+                if (have) continue;
+                uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0, v2 = v0, v3 = v0;
+                if (hx >= 0 && hx < WS && hy >= 0 && hy < hbRows) {
+                    const uint4* src =
+                        reinterpret_cast<const uint4*>(plane + ((size_t)(hy >> 1) * WS + hx) * 32 + (hy & 1) * 16);
+                    v0 = src[0]; v1 = src[1]; v2 = src[2]; v3 = src[3];
+                }
+                uint32_t* dst = tile + (((hy & 1) * 16) * 2 + (hx & 1)) * 64 + lane;  // row stride 128 words
+                dst[0 * 128] = v0.x; dst[1 * 128] = v0.y; dst[2 * 128] = v0.z; dst[3 * 128] = v0.w;
+                dst[4 * 128] = v1.x; dst[5 * 128] = v1.y; dst[6 * 128] = v1.z; dst[7 * 128] = v1.w;
+                dst[8 * 128] = v2.x; dst[9 * 128] = v2.y; dst[10 * 128] = v2.z; dst[11 * 128] = v2.w;
+                dst[12 * 128] = v3.x; dst[13 * 128] = v3.y; dst[14 * 128] = v3.z; dst[15 * 128] = v3.w;
+            }
+        }
+        gx = ngx;
+        gy = ngy;
+        valid = true;
+    }
+    __device__ __forceinline__ uint32_t mask(const uint32_t* __restrict__ tile, int lane, int x, int y) const {
+        const int wa = ((x - 1) >> 5) & 1, wb = ((x + 1) >> 5) & 1, sh = (x - 1) & 31;
+        uint32_t f[3];
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            const uint32_t* row = tile + (((y - 1 + r) & 31) * 2) * 64 + lane;
+            uint64_t v = row[wa * 64];
+            if (wb != wa) v |= (uint64_t)row[wb * 64] << 32;
+            f[r] = (uint32_t)(v >> sh) & 7u;
+        }
+        return pack_mask(f[0], f[1], f[2]);
+    }
+};
+
+// STORE = false: decide the long candidates (canonical start? length within bounds?) and reserve pool space.
+// STORE = true : write the points of the accepted contours.
+template <bool STORE>
+__global__ __launch_bounds__(64) void k_trace_tile(const uint32_t* __restrict__ planes, DetCfg cfg,
+                                                   const uint64_t* __restrict__ candLong, unsigned int candCap,
+                                                   ContourRec* __restrict__ contours, unsigned int contourCap,
+                                                   uint32_t* __restrict__ pool, unsigned int poolCap,
+                                                   Counters* __restrict__ ctr) {
+    __shared__ uint32_t tile[32 * 2 * 64];
+    const int lane = threadIdx.x;
+    const unsigned int n = STORE ? min(ctr->nContours, contourCap) : min(ctr->nLong, candCap);
+    unsigned int* qhead = STORE ? &ctr->qStore : &ctr->qDecide;
     const int H = cfg.H, W = cfg.W, WS = cfg.WS, S = cfg.nScales;
-    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const ContourRec r = contours[i];
-        const uint32_t* plane = planes + ((size_t)r.frame * S + r.scale) * (size_t)H * WS;
-        store_border(plane, WS, r.pos % W, r.pos / W, r.hole != 0, (int)r.len, pool + r.off);
+    const size_t perPlane = plane_words(H, WS);
+
+    bool active = false, exhausted = false, fresh = false, isHole = false;
+    uint64_t c = 0;
+    int limit = 0, count = 0, startKey = 0;
+    int x0 = 1, y0 = 1, x1 = 1, y1 = 1, cx = 1, cy = 1, s = 0;
+    uint32_t* out = nullptr;
+    const uint32_t* plane = planes;
+    TileWin win;
+    win.gx = win.gy = 0;
+    win.valid = false;
+
+    for (;;) {
+        // ---- idle lanes fetch their next border (the queue only ever hands out indices below n once) ----
+        const bool need = !active && !exhausted;
+        const unsigned long long bal = __ballot(need);
+        if (bal) {
+            const int leader = __ffsll((long long)bal) - 1;
+            unsigned int qb = 0;
+            if (lane == leader) qb = atomicAdd(qhead, (unsigned int)__popcll(bal));
+            qb = __shfl(qb, leader, 64);
+            if (need) {
+                const unsigned int i = qb + (unsigned int)__popcll(bal & ((1ull << lane) - 1ull));
+                if (i < n) {
+                    if (STORE) {
+                        const ContourRec r = contours[i];
+                        plane = planes + ((size_t)r.frame * S + r.scale) * perPlane;
+                        x0 = (int)(r.pos % W);
+                        y0 = (int)(r.pos / W);
+                        isHole = r.hole != 0;
+                        limit = (int)r.len;
+                        out = pool + r.off;
+                    } else {
+                        c = candLong[i];
+                        const uint32_t pos = (uint32_t)(c & 0xFFFFFFFFull);
+                        plane = planes + ((size_t)(uint32_t)(c >> 40) * S + (int)((c >> 36) & 7u)) * perPlane;
+                        x0 = (int)(pos % W);
+                        y0 = (int)(pos / W);
+                        isHole = (c >> 39) & 1u;
+                        limit = cfg.maxPerim + 1;  // one more point than allowed shows the border is too long
+                    }
+                    cx = x0;
+                    cy = y0;
+                    startKey = y0 * W + x0;
+                    count = 0;
+                    win.valid = false;
+                    active = true;
+                    fresh = true;
+                } else {
+                    exhausted = true;
+                }
+            }
+        }
+        if (!__any(active)) break;
+
+        // ---- keep every active lane's window around its pixel ----
+        if (__any(active && !win.covers(cx, cy))) {
+            if (active) win.recentre(plane, WS, H, cx, cy, tile, lane);
+        }
+
+        if (active) {
+            const uint32_t m = win.mask(tile, lane, cx, cy);
+            int res = -1;  // -1 keep going, 0 drop, >0 closed with that many points
+            if (fresh) {
+                // initial clockwise search for the neighbour the border closes through
+                fresh = false;
+                const int s_end = isHole ? 0 : 4;
+                s = s_end;
+                bool found = false;
+                for (int k = 0; k < 8; k++) {
+                    s = (s - 1) & 7;
+                    if (s == s_end) break;
+                    if ((m >> s) & 1u) { found = true; break; }
+                }
+                x1 = x0 + dir_dx(s);
+                y1 = y0 + dir_dy(s);
+                if (!found) {  // single pixel (never reaches these lists; kept for completeness)
+                    if (STORE) out[0] = (uint32_t)x0 | ((uint32_t)y0 << 16);
+                    res = 1;
+                }
+            }
+            if (res < 0) {
+                const int s_end = s;
+                const uint32_t rot = ((m >> (s_end + 1)) | (m << (7 - s_end))) & 0xFFu;
+                const int k = __ffs(rot);
+                const int sn = (s_end + k) & 7;
+                if (!STORE && (isHole ? (s_end + k >= 9) : true) && cy * W + cx < startKey) {
+                    res = 0;  // not the canonical start of this border
+                } else {
+                    if (STORE) out[count] = (uint32_t)cx | ((uint32_t)cy << 16);
+                    count++;
+                    const int nx = cx + dir_dx(sn), ny = cy + dir_dy(sn);
+                    if (nx == x0 && ny == y0 && cx == x1 && cy == y1) {
+                        res = count;
+                    } else if (count >= limit) {
+                        res = 0;
+                    } else {
+                        cx = nx;
+                        cy = ny;
+                        s = (sn + 4) & 7;
+                    }
+                }
+            }
+            if (res >= 0) {
+                active = false;
+                if (!STORE && res >= cfg.minPerim && res <= cfg.maxPerim) emit_contour(c, res, contours, contourCap, poolCap, ctr);
+            }
+        }
     }
 }
 
 }  // namespace
 
 void launch_contour_starts(const DetCfg& c, const DetBuffers& b, int B, hipStream_t st) {
-    const size_t total = (size_t)B * c.nScales * c.H * c.WS;
+    const size_t total = (size_t)B * c.nScales * plane_words(c.H, c.WS);
     const size_t nblk = (total + 255) / 256;
     const unsigned blocks = (unsigned)(nblk < (size_t)(256 * 16) ? nblk : (size_t)(256 * 16));
     hipLaunchKernelGGL(k_contour_starts, dim3(blocks), dim3(256), 0, st, b.planes, c, B, b.cand, b.candCap, b.counters);
 }
 
 void launch_trace(const DetCfg& c, const DetBuffers& b, hipStream_t st) {
-    hipLaunchKernelGGL(k_trace<false>, dim3(256 * 8), dim3(256), 0, st, b.planes, c, b.cand, b.candCap, b.candLong,
+    hipLaunchKernelGGL(k_trace_short, dim3(256 * 8), dim3(256), 0, st, b.planes, c, b.cand, b.candCap, b.candLong,
                        b.contours, b.contourCap, b.poolCap, b.counters);
-    hipLaunchKernelGGL(k_trace<true>, dim3(256 * 8), dim3(64), 0, st, b.planes, c, b.candLong, b.candCap, b.candLong,
-                       b.contours, b.contourCap, b.poolCap, b.counters);
-    hipLaunchKernelGGL(k_trace_store, dim3(256 * 8), dim3(64), 0, st, b.planes, c, b.contours, b.contourCap, b.pool,
-                       b.counters);
+    // persistent: 10 single-wave workgroups per CU (16 KiB of LDS each)
+    hipLaunchKernelGGL(k_trace_tile<false>, dim3(256 * 10), dim3(64), 0, st, b.planes, c, b.candLong, b.candCap, b.contours,
+                       b.contourCap, b.pool, b.poolCap, b.counters);
+    hipLaunchKernelGGL(k_trace_tile<true>, dim3(256 * 10), dim3(64), 0, st, b.planes, c, b.candLong, b.candCap, b.contours,
+                       b.contourCap, b.pool, b.poolCap, b.counters);
 }
 
 }  // namespace camsync

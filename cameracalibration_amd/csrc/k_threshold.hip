@@ -223,16 +223,25 @@ __global__ __launch_bounds__(TPB) void k_gray_thresh3(const uint8_t* __restrict_
             if (y == 0 || y == H - 1) keep = 0;
             if (xbase == 0) keep &= 0xFEu;
             if (xbase + 7 >= W - 1) keep &= ~(1u << ((W - 1) - xbase)) & ((W - xbase) >= 8 ? 0xFFu : ((1u << (W - xbase)) - 1u));
-            const size_t rowBytes = (size_t)WS * 4;
-            uint8_t* pl = reinterpret_cast<uint8_t*>(planes) + ((size_t)f * 3 * H + y) * rowBytes + (xbase >> 3);
-            const size_t planeBytes = (size_t)H * rowBytes;
+            // block-linear layout (internal.h): byte b of word (xw, y)
+            const size_t planeBytes = plane_words(H, WS) * 4;
+            uint8_t* pbase = reinterpret_cast<uint8_t*>(planes) + (size_t)f * 3 * planeBytes;
+            uint8_t* pl = pbase + plane_word_index(WS, xbase >> 5, y) * 4 + ((xbase >> 3) & 3);
             pl[0] = (uint8_t)(pm0 & keep);
             pl[planeBytes] = (uint8_t)(pm1 & keep);
             pl[2 * planeBytes] = (uint8_t)(pm2 & keep);
-            if (xbase + 8 >= W) {  // last byte of the row: clear the row padding
-                for (int pb = (xbase >> 3) + 1; pb < (int)rowBytes; pb++) {
-                    uint8_t* q = reinterpret_cast<uint8_t*>(planes) + ((size_t)f * 3 * H + y) * rowBytes + pb;
+            if (xbase + 8 >= W) {  // last byte of the row: clear the padding bytes of its word
+                for (int b = ((xbase >> 3) & 3) + 1; b < 4; b++) {
+                    uint8_t* q = pl + (b - ((xbase >> 3) & 3));
                     q[0] = 0; q[planeBytes] = 0; q[2 * planeBytes] = 0;
+                }
+            }
+            if (y == H - 1) {  // last image row: clear the padding rows of the last block row
+                for (int yy = H; yy < plane_hb(H) * 32; yy++) {
+                    for (int b = (xbase >> 3) & 3; b < ((xbase + 8 >= W) ? 4 : ((xbase >> 3) & 3) + 1); b++) {
+                        uint8_t* q = pbase + plane_word_index(WS, xbase >> 5, yy) * 4 + b;
+                        q[0] = 0; q[planeBytes] = 0; q[2 * planeBytes] = 0;
+                    }
                 }
             }
         }
@@ -259,7 +268,7 @@ __global__ void k_thresh_generic(const uint8_t* __restrict__ gray, uint8_t* __re
     const int y = (int)((i / W8) % H);
     const size_t f = i / ((size_t)W8 * H);
     const uint8_t* g = gray + f * (size_t)W * H;
-    const size_t rowBytes = (size_t)cfg.WS * 4, planeBytes = (size_t)H * rowBytes;
+    const size_t planeBytes = plane_words(H, cfg.WS) * 4;
     uint32_t pm[kMaxScales];
     for (int s = 0; s < cfg.nScales; s++) pm[s] = 0;
     for (int k = 0; k < 8; k++) {
@@ -285,11 +294,14 @@ __global__ void k_thresh_generic(const uint8_t* __restrict__ gray, uint8_t* __re
         }
         if (bin) bin[f * (size_t)W * H + (size_t)y * W + x] = (uint8_t)m;
     }
-    uint8_t* pl = reinterpret_cast<uint8_t*>(planes) + (f * cfg.nScales * H + y) * rowBytes + xb;
+    uint8_t* pbase = reinterpret_cast<uint8_t*>(planes) + f * cfg.nScales * planeBytes;
+    const int b0 = xb & 3, b1 = (xb == W8 - 1) ? 4 : b0 + 1;  // the row's last byte also clears its word's padding
     for (int s = 0; s < cfg.nScales; s++) {
-        pl[s * planeBytes] = (uint8_t)pm[s];
-        if (xb == W8 - 1)
-            for (int pb = 1; xb + pb < (int)rowBytes; pb++) pl[s * planeBytes + pb] = 0;
+        for (int b = b0; b < b1; b++)
+            pbase[s * planeBytes + plane_word_index(cfg.WS, xb >> 2, y) * 4 + b] = (b == b0) ? (uint8_t)pm[s] : (uint8_t)0;
+        if (y == H - 1)
+            for (int yy = H; yy < plane_hb(H) * 32; yy++)
+                for (int b = b0; b < b1; b++) pbase[s * planeBytes + plane_word_index(cfg.WS, xb >> 2, yy) * 4 + b] = 0;
     }
 }
 
