@@ -405,9 +405,15 @@ struct TileWin {
     int gx, gy;  // window origin in half-block units: columns [32 gx, 32 gx + 64), rows [16 gy, 16 gy + 32)
     bool valid;
 
+    // the 3x3 neighbourhood of (x, y) lies inside the window
     __device__ __forceinline__ bool covers(int x, int y) const {
-        return valid && ((x - 1) >> 5) >= gx && ((x + 1) >> 5) <= gx + 1 && ((y - 1) >> 4) >= gy && ((y + 1) >> 4) <= gy + 1;
+        return valid && (unsigned)(x - (gx << 5) - 1) < 62u && (unsigned)(y - (gy << 4) - 1) < 30u;
     }
+    // closer than 12 columns / 6 rows to leaving the window (never true right after recentre())
+    __device__ __forceinline__ bool near_edge(int x, int y) const {
+        return !(valid && (unsigned)(x - (gx << 5) - 12) < 40u && (unsigned)(y - (gy << 4) - 6) < 20u);
+    }
+    // tile word index: (row * 64 + lane) * 2 + column, i.e. one 64-bit read fetches both words of a row
     __device__ __forceinline__ void recentre(const uint32_t* __restrict__ plane, int WS, int H, int x, int y,
                                              uint32_t* __restrict__ tile, int lane) {
         const int ngx = (x - 16) >> 5, ngy = (y - 8) >> 4;
@@ -425,7 +431,7 @@ struct TileWin {
                         reinterpret_cast<const uint4*>(plane + ((size_t)(hy >> 1) * WS + hx) * 32 + (hy & 1) * 16);
                     v0 = src[0]; v1 = src[1]; v2 = src[2]; v3 = src[3];
                 }
-                uint32_t* dst = tile + (((hy & 1) * 16) * 2 + (hx & 1)) * 64 + lane;  // row stride 128 words
+                uint32_t* dst = tile + ((hy & 1) * 16) * 128 + lane * 2 + (hx & 1);  // row stride 128 words
                 dst[0 * 128] = v0.x; dst[1 * 128] = v0.y; dst[2 * 128] = v0.z; dst[3 * 128] = v0.w;
                 dst[4 * 128] = v1.x; dst[5 * 128] = v1.y; dst[6 * 128] = v1.z; dst[7 * 128] = v1.w;
                 dst[8 * 128] = v2.x; dst[9 * 128] = v2.y; dst[10 * 128] = v2.z; dst[11 * 128] = v2.w;
@@ -437,18 +443,22 @@ struct TileWin {
         valid = true;
     }
     __device__ __forceinline__ uint32_t mask(const uint32_t* __restrict__ tile, int lane, int x, int y) const {
-        const int wa = ((x - 1) >> 5) & 1, wb = ((x + 1) >> 5) & 1, sh = (x - 1) & 31;
-        uint32_t f[3];
-#pragma unroll
-        for (int r = 0; r < 3; r++) {
-            const uint32_t* row = tile + (((y - 1 + r) & 31) * 2) * 64 + lane;
-            uint64_t v = row[wa * 64];
-            if (wb != wa) v |= (uint64_t)row[wb * 64] << 32;
-            f[r] = (uint32_t)(v >> sh) & 7u;
-        }
-        return pack_mask(f[0], f[1], f[2]);
+        const uint2* t2 = reinterpret_cast<const uint2*>(tile) + lane;
+        const int xm = x - 1;
+        const bool swap = (xm >> 5) & 1;
+        const uint2 r0 = t2[((y - 1) & 31) * 64], r1 = t2[(y & 31) * 64], r2 = t2[((y + 1) & 31) * 64];
+        // funnel shift of (next word : this word) by xm & 31 brings pixel x-1 to bit 0
+        const uint32_t t = __funnelshift_r(swap ? r0.y : r0.x, swap ? r0.x : r0.y, xm) & 7u;
+        const uint32_t m = __funnelshift_r(swap ? r1.y : r1.x, swap ? r1.x : r1.y, xm) & 7u;
+        const uint32_t u = __funnelshift_r(swap ? r2.y : r2.x, swap ? r2.x : r2.y, xm) & 7u;
+        // same bit order as pack_mask: NE,N,NW are the row above reversed
+        return (__brev(t) >> 28) | ((m >> 2) & 1u) | ((m & 1u) << 4) | (u << 5);
     }
 };
+
+// direction -> step, two bits per direction holding d + 1
+__device__ __forceinline__ int fast_dx(int d) { return (int)((0x901Au >> (2 * d)) & 3u) - 1; }
+__device__ __forceinline__ int fast_dy(int d) { return (int)((0xA901u >> (2 * d)) & 3u) - 1; }
 
 // STORE = false: decide the long candidates (canonical start? length within bounds?) and reserve pool space.
 // STORE = true : write the points of the accepted contours.
@@ -458,7 +468,7 @@ __global__ __launch_bounds__(64) void k_trace_tile(const uint32_t* __restrict__ 
                                                    ContourRec* __restrict__ contours, unsigned int contourCap,
                                                    uint32_t* __restrict__ pool, unsigned int poolCap,
                                                    Counters* __restrict__ ctr) {
-    __shared__ uint32_t tile[32 * 2 * 64];
+    __shared__ __align__(8) uint32_t tile[32 * 2 * 64];
     const int lane = threadIdx.x;
     const unsigned int n = STORE ? min(ctr->nContours, contourCap) : min(ctr->nLong, candCap);
     unsigned int* qhead = STORE ? &ctr->qStore : &ctr->qDecide;
@@ -476,7 +486,7 @@ __global__ __launch_bounds__(64) void k_trace_tile(const uint32_t* __restrict__ 
     win.valid = false;
 
     for (;;) {
-        // ---- idle lanes fetch their next border (the queue only ever hands out indices below n once) ----
+        // ---- idle lanes fetch their next border (the queue hands out every index below n exactly once) ----
         const bool need = !active && !exhausted;
         const unsigned long long bal = __ballot(need);
         if (bal) {
@@ -519,42 +529,39 @@ __global__ __launch_bounds__(64) void k_trace_tile(const uint32_t* __restrict__ 
         if (!__any(active)) break;
 
         // ---- keep every active lane's window around its pixel ----
+        // (a re-centred window leaves >= 16 columns / 8 rows of margin; when one lane must move, every lane
+        // that is close to its edge moves too, so the wave pays the load latency once per several steps)
         if (__any(active && !win.covers(cx, cy))) {
-            if (active) win.recentre(plane, WS, H, cx, cy, tile, lane);
+            if (active && win.near_edge(cx, cy)) win.recentre(plane, WS, H, cx, cy, tile, lane);
         }
 
         if (active) {
             const uint32_t m = win.mask(tile, lane, cx, cy);
             int res = -1;  // -1 keep going, 0 drop, >0 closed with that many points
             if (fresh) {
-                // initial clockwise search for the neighbour the border closes through
+                // initial clockwise search (s_end-1, s_end-2, ...) for the neighbour the border closes through:
+                // rotate so that bit j is direction s_end + j, the first hit clockwise is the highest of bits 1..7
                 fresh = false;
                 const int s_end = isHole ? 0 : 4;
-                s = s_end;
-                bool found = false;
-                for (int k = 0; k < 8; k++) {
-                    s = (s - 1) & 7;
-                    if (s == s_end) break;
-                    if ((m >> s) & 1u) { found = true; break; }
-                }
-                x1 = x0 + dir_dx(s);
-                y1 = y0 + dir_dy(s);
-                if (!found) {  // single pixel (never reaches these lists; kept for completeness)
+                const uint32_t r = ((m >> s_end) | (m << (8 - s_end))) & 0xFEu;
+                s = r ? ((s_end + 31 - __clz(r)) & 7) : s_end;
+                x1 = x0 + fast_dx(s);
+                y1 = y0 + fast_dy(s);
+                if (!r) {  // single pixel (never reaches these lists; kept for completeness)
                     if (STORE) out[0] = (uint32_t)x0 | ((uint32_t)y0 << 16);
                     res = 1;
                 }
             }
             if (res < 0) {
-                const int s_end = s;
-                const uint32_t rot = ((m >> (s_end + 1)) | (m << (7 - s_end))) & 0xFFu;
-                const int k = __ffs(rot);
-                const int sn = (s_end + k) & 7;
-                if (!STORE && (isHole ? (s_end + k >= 9) : true) && cy * W + cx < startKey) {
-                    res = 0;  // not the canonical start of this border
+                const uint32_t rot = ((m >> (s + 1)) | (m << (7 - s))) & 0xFFu;  // bit j <-> direction s+1+j
+                const int k = __ffs(rot);  // 1..8: m always holds the neighbour we came from
+                const int sn = (s + k) & 7;
+                if (!STORE && (!isHole || s + k >= 9) && cy * W + cx < startKey) {
+                    res = 0;  // a crack of this border has a smaller raster key: not the canonical start
                 } else {
                     if (STORE) out[count] = (uint32_t)cx | ((uint32_t)cy << 16);
                     count++;
-                    const int nx = cx + dir_dx(sn), ny = cy + dir_dy(sn);
+                    const int nx = cx + fast_dx(sn), ny = cy + fast_dy(sn);
                     if (nx == x0 && ny == y0 && cx == x1 && cy == y1) {
                         res = count;
                     } else if (count >= limit) {
@@ -562,7 +569,7 @@ __global__ __launch_bounds__(64) void k_trace_tile(const uint32_t* __restrict__ 
                     } else {
                         cx = nx;
                         cy = ny;
-                        s = (sn + 4) & 7;
+                        s = sn ^ 4;
                     }
                 }
             }
