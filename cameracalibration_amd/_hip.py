@@ -17,6 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcamsync_hip.so")
 
 N_STAGES = 9
+E_ARG, E_HIP, E_CAPACITY, E_NODEVICE, E_NUMERIC = -1, -2, -3, -4, -5  # include/camsync.h
 STAGE_NAMES = ("gray_threshold", "contour_starts", "trace", "quad_fit", "identify", "select", "subpix", "pnp", "total")
 
 
@@ -143,7 +144,8 @@ class Context:
         self._h = C.c_void_p()
         rc = self._lib.camsync_create(C.byref(self._h), device, max_h, max_w, max_batch)
         if rc != 0:
-            msg = self._lib.camsync_last_error(self._h).decode() if self._h else "no usable GPU"
+            msg = self._lib.camsync_last_error(self._h).decode() if self._h else (
+                "no usable GPU" if rc == E_NODEVICE else "bad context size (max_h, max_w >= 32, max_batch >= 1)")
             if self._h:
                 self._lib.camsync_destroy(self._h)
                 self._h = C.c_void_p()
@@ -371,6 +373,7 @@ _ctx_lock = threading.Lock()
 
 def get_context(h: int, w: int, batch: int = 1, device: int = 0) -> Context:
     """A cached context large enough for (batch, h, w) frames on `device`."""
+    h, w = max(h, 32), max(w, 32)
     with _ctx_lock:
         key = device
         ctx = _default_ctx.get(key)

@@ -127,6 +127,24 @@ double orc_calibrate(const double* obj, const double* img, int V, int P, int W, 
                      int flags, int max_iter, double K_out[9], double* dist_out,
                      double* rvecs, double* tvecs, int32_t* iters_out);
 
+/* K12 in pieces, for the multi-process tests: the same arithmetic as orc_calibrate split the way
+ * the distributed driver (cameracalibration_amd/calibrate_dist.py) needs it.  Each handle owns a
+ * contiguous share of the views; everything returned is a SUM over the handle's views, so summing over
+ * handles (the all-reduce) gives the global quantity.
+ *   focal_acc : [AtA00, AtA01, AtA11, Atb0, Atb1, 0] of cvInitIntrinsicParams2D's 2x2 system
+ *   accumulate: [S (NI x NI) | rhs (NI) | err] — the extrinsic blocks eliminated (Schur complement),
+ *               diagonals scaled by (1 + lambda) as CvLevMarq does
+ *   step      : trial = current - delta (intrinsics, back-substituted extrinsics); returns the trial error
+ */
+void* orc_calib_begin(const double* obj, const double* img, int V, int P, int flags);
+void orc_calib_end(void* h);
+void orc_calib_focal_acc(void* h, int W, int H, double acc6[6]);
+void orc_calib_set_intrinsics(void* h, const double intr[12], int init_extrinsics);
+void orc_calib_accumulate(void* h, double lambda, double* acc);
+double orc_calib_step(void* h, const double* delta);
+void orc_calib_accept(void* h);
+void orc_calib_get(void* h, double intr[12], double* rvecs, double* tvecs);
+
 #ifdef __cplusplus
 }
 #endif

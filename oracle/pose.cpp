@@ -1029,3 +1029,181 @@ extern "C" double orc_calibrate(const double* obj, const double* img, int V, int
     (void)chol_solve;
     return sqrt(total / ((double)V * P));
 }
+
+/* ---------------------------------------------- K12 split per share of views
+ * (oracle.h: orc_calib_*).  Same formulas as orc_calibrate above, arranged so that
+ * every output is additive over disjoint sets of views. */
+namespace {
+
+struct CalibShare {
+    int V, P, NI;
+    std::vector<double> obj, img, intr, ext, intrT, extT, AinvBt, Ainvg;
+};
+
+void unpack_intr(const double* p, int NI, double fxy[2], double cxy[2], double k[8]) {
+    fxy[0] = p[0]; fxy[1] = p[1]; cxy[0] = p[2]; cxy[1] = p[3];
+    for (int i = 0; i < 8; i++) k[i] = (i < NI - 4) ? p[4 + i] : 0.;
+}
+
+double share_error(const CalibShare& s, const double* intr, const double* ext) {
+    double fxy[2], cxy[2], k[8], total = 0;
+    unpack_intr(intr, s.NI, fxy, cxy, k);
+    std::vector<double> proj((size_t)2 * s.P);
+    for (int v = 0; v < s.V; v++) {
+        const double* rt = ext + 6 * v;
+        project_points(&s.obj[(size_t)v * s.P * 3], s.P, rt, rt + 3, fxy, cxy, k, proj.data(), 0, 0, 0, 0, 0);
+        for (int i = 0; i < 2 * s.P; i++) {
+            const double e = proj[i] - s.img[(size_t)v * s.P * 2 + i];
+            total += e * e;
+        }
+    }
+    return total;
+}
+
+}  // namespace
+
+extern "C" {
+
+void* orc_calib_begin(const double* obj, const double* img, int V, int P, int flags) {
+    CalibShare* s = new CalibShare;
+    s->V = V; s->P = P; s->NI = (flags & 1) ? 12 : 9;
+    s->obj.assign(obj, obj + (size_t)V * P * 3);
+    s->img.assign(img, img + (size_t)V * P * 2);
+    s->intr.assign(12, 0.); s->intrT.assign(12, 0.);
+    s->ext.assign((size_t)V * 6, 0.); s->extT.assign((size_t)V * 6, 0.);
+    s->AinvBt.assign((size_t)V * 6 * s->NI, 0.); s->Ainvg.assign((size_t)V * 6, 0.);
+    return s;
+}
+
+void orc_calib_end(void* h) { delete static_cast<CalibShare*>(h); }
+
+void orc_calib_focal_acc(void* h, int W, int Hh, double acc6[6]) {
+    const CalibShare& s = *static_cast<CalibShare*>(h);
+    const double cx = (!W) ? 0.5 : (W - 1) * 0.5, cy = (!Hh) ? 0.5 : (Hh - 1) * 0.5;
+    for (int i = 0; i < 6; i++) acc6[i] = 0;
+    std::vector<double> Mxy((size_t)2 * s.P);
+    for (int v = 0; v < s.V; v++) {
+        for (int j = 0; j < s.P; j++) {
+            Mxy[2 * j] = s.obj[((size_t)v * s.P + j) * 3];
+            Mxy[2 * j + 1] = s.obj[((size_t)v * s.P + j) * 3 + 1];
+        }
+        double H[9];
+        if (!find_homography(Mxy.data(), &s.img[(size_t)v * s.P * 2], s.P, H)) continue;
+        H[0] -= H[6] * cx; H[1] -= H[7] * cx; H[2] -= H[8] * cx;
+        H[3] -= H[6] * cy; H[4] -= H[7] * cy; H[5] -= H[8] * cy;
+        double hh[3], vv[3], d1[3], d2[3], n[4] = {0, 0, 0, 0};
+        for (int j = 0; j < 3; j++) {
+            const double t0 = H[j * 3], t1 = H[j * 3 + 1];
+            hh[j] = t0; vv[j] = t1; d1[j] = (t0 + t1) * 0.5; d2[j] = (t0 - t1) * 0.5;
+            n[0] += t0 * t0; n[1] += t1 * t1; n[2] += d1[j] * d1[j]; n[3] += d2[j] * d2[j];
+        }
+        for (int j = 0; j < 4; j++) n[j] = 1. / sqrt(n[j]);
+        for (int j = 0; j < 3; j++) { hh[j] *= n[0]; vv[j] *= n[1]; d1[j] *= n[2]; d2[j] *= n[3]; }
+        const double A0[2] = {hh[0] * vv[0], hh[1] * vv[1]}, A1[2] = {d1[0] * d2[0], d1[1] * d2[1]};
+        const double b0 = -hh[2] * vv[2], b1 = -d1[2] * d2[2];
+        acc6[0] += A0[0] * A0[0] + A1[0] * A1[0];
+        acc6[1] += A0[0] * A0[1] + A1[0] * A1[1];
+        acc6[2] += A0[1] * A0[1] + A1[1] * A1[1];
+        acc6[3] += A0[0] * b0 + A1[0] * b1;
+        acc6[4] += A0[1] * b0 + A1[1] * b1;
+    }
+}
+
+void orc_calib_set_intrinsics(void* h, const double intr[12], int init_extrinsics) {
+    CalibShare& s = *static_cast<CalibShare*>(h);
+    s.intr.assign(intr, intr + 12);
+    if (!init_extrinsics) return;
+    const double a[9] = {intr[0], 0, intr[2], 0, intr[1], intr[3], 0, 0, 1};
+    const double k0[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int v = 0; v < s.V; v++)
+        find_extrinsics(&s.obj[(size_t)v * s.P * 3], &s.img[(size_t)v * s.P * 2], s.P, a, k0, &s.ext[(size_t)6 * v]);
+}
+
+void orc_calib_accumulate(void* h, double lambda, double* acc) {
+    CalibShare& s = *static_cast<CalibShare*>(h);
+    const int NI = s.NI, P = s.P;
+    double fxy[2], cxy[2], k[8];
+    unpack_intr(s.intr.data(), NI, fxy, cxy, k);
+    double* S = acc;
+    double* rhs = acc + NI * NI;
+    for (int i = 0; i < NI * NI + NI + 1; i++) acc[i] = 0;
+    std::vector<double> proj((size_t)2 * P), dpdr((size_t)2 * P * 3), dpdt((size_t)2 * P * 3), dpdf((size_t)2 * P * 2),
+        dpdc((size_t)2 * P * 2), dpdk((size_t)2 * P * 8), Ji((size_t)2 * P * NI), Je((size_t)2 * P * 6), err((size_t)2 * P);
+    for (int v = 0; v < s.V; v++) {
+        const double* rt = &s.ext[(size_t)6 * v];
+        project_points(&s.obj[(size_t)v * P * 3], P, rt, rt + 3, fxy, cxy, k, proj.data(), dpdr.data(), dpdt.data(),
+                       dpdf.data(), dpdc.data(), dpdk.data());
+        double Aii[144] = {0}, gi[12] = {0}, B[72] = {0}, A[36] = {0}, g[6] = {0};
+        for (int i = 0; i < 2 * P; i++) {
+            err[i] = proj[i] - s.img[(size_t)v * P * 2 + i];
+            acc[NI * NI + NI] += err[i] * err[i];
+            double* ji = &Ji[(size_t)i * NI];
+            ji[0] = dpdf[i * 2]; ji[1] = dpdf[i * 2 + 1]; ji[2] = dpdc[i * 2]; ji[3] = dpdc[i * 2 + 1];
+            for (int q = 0; q < NI - 4; q++) ji[4 + q] = dpdk[(size_t)i * 8 + q];
+            double* je = &Je[(size_t)i * 6];
+            for (int q = 0; q < 3; q++) { je[q] = dpdr[(size_t)i * 3 + q]; je[3 + q] = dpdt[(size_t)i * 3 + q]; }
+            for (int r = 0; r < NI; r++) {
+                gi[r] += ji[r] * err[i];
+                for (int c = 0; c < NI; c++) Aii[r * NI + c] += ji[r] * ji[c];
+                for (int c = 0; c < 6; c++) B[r * 6 + c] += ji[r] * je[c];
+            }
+            for (int r = 0; r < 6; r++) {
+                g[r] += je[r] * err[i];
+                for (int c = 0; c < 6; c++) A[r * 6 + c] += je[r] * je[c];
+            }
+        }
+        for (int r = 0; r < NI; r++) Aii[r * NI + r] *= 1. + lambda;
+        for (int r = 0; r < 6; r++) A[r * 6 + r] *= 1. + lambda;
+        double* AinvBt = &s.AinvBt[(size_t)v * 6 * NI];
+        double* Ainvg = &s.Ainvg[(size_t)v * 6];
+        for (int c = 0; c < NI; c++) {
+            double bcol[6], x[6];
+            for (int r = 0; r < 6; r++) bcol[r] = B[c * 6 + r];
+            solve_sym(A, bcol, 6, x);
+            for (int r = 0; r < 6; r++) AinvBt[r * NI + c] = x[r];
+        }
+        solve_sym(A, g, 6, Ainvg);
+        for (int r = 0; r < NI; r++) {
+            double sg = 0;
+            for (int q = 0; q < 6; q++) sg += B[r * 6 + q] * Ainvg[q];
+            rhs[r] += gi[r] - sg;
+            for (int c = 0; c < NI; c++) {
+                double t = 0;
+                for (int q = 0; q < 6; q++) t += B[r * 6 + q] * AinvBt[q * NI + c];
+                S[r * NI + c] += Aii[r * NI + c] - t;
+            }
+        }
+    }
+}
+
+double orc_calib_step(void* h, const double* delta) {
+    CalibShare& s = *static_cast<CalibShare*>(h);
+    const int NI = s.NI;
+    s.intrT = s.intr;
+    for (int r = 0; r < NI; r++) s.intrT[r] = s.intr[r] - delta[r];
+    for (int v = 0; v < s.V; v++)
+        for (int q = 0; q < 6; q++) {
+            double t = s.Ainvg[(size_t)v * 6 + q];
+            for (int c = 0; c < NI; c++) t -= s.AinvBt[((size_t)v * 6 + q) * NI + c] * delta[c];
+            s.extT[(size_t)6 * v + q] = s.ext[(size_t)6 * v + q] - t;
+        }
+    return share_error(s, s.intrT.data(), s.extT.data());
+}
+
+void orc_calib_accept(void* h) {
+    CalibShare& s = *static_cast<CalibShare*>(h);
+    s.intr = s.intrT;
+    s.ext = s.extT;
+}
+
+void orc_calib_get(void* h, double intr[12], double* rvecs, double* tvecs) {
+    const CalibShare& s = *static_cast<CalibShare*>(h);
+    if (intr) for (int i = 0; i < 12; i++) intr[i] = s.intr[i];
+    for (int v = 0; v < s.V; v++)
+        for (int q = 0; q < 3; q++) {
+            if (rvecs) rvecs[3 * v + q] = s.ext[(size_t)6 * v + q];
+            if (tvecs) tvecs[3 * v + q] = s.ext[(size_t)6 * v + 3 + q];
+        }
+}
+
+}  /* extern "C" */

@@ -182,3 +182,55 @@ def calibrate(obj, img, image_size, rational=False, max_iter=30):
     rms = lib().orc_calibrate(_p(obj), _p(img), V, P, W, H, 1 if rational else 0, max_iter, _p(K), _p(dist), _p(rv), _p(tv),
                               C.byref(iters))
     return rms, K, dist, rv, tv, iters.value
+
+
+class CalibShare:
+    """A share of views held by the oracle's orc_calib_* pieces; same interface as
+    cameracalibration_amd.calibrate_dist.HipCalibWorker, so the distributed driver can be run on CPU."""
+
+    def __init__(self, obj, img, rational=False):
+        L = lib()
+        L.orc_calib_begin.restype = C.c_void_p
+        L.orc_calib_step.restype = C.c_double
+        for f in (L.orc_calib_end, L.orc_calib_focal_acc, L.orc_calib_set_intrinsics, L.orc_calib_accumulate,
+                  L.orc_calib_step, L.orc_calib_accept, L.orc_calib_get):
+            f.argtypes = None
+        obj = np.ascontiguousarray(np.asarray(obj, np.float32).astype(np.float64))
+        self.V, self.points_per_view = obj.shape[0], obj.shape[1]
+        img = np.ascontiguousarray(np.asarray(img, np.float32).astype(np.float64)).reshape(self.V, self.points_per_view, 2)
+        self.ni = 12 if rational else 9
+        self._h = C.c_void_p(L.orc_calib_begin(_p(obj), _p(img), self.V, self.points_per_view, 1 if rational else 0))
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                lib().orc_calib_end(self._h)
+                self._h = None
+        except Exception:  # interpreter shutdown
+            pass
+
+    def focal_acc(self, W, H):
+        a = np.zeros(6)
+        lib().orc_calib_focal_acc(self._h, int(W), int(H), _p(a))
+        return a
+
+    def set_intrinsics(self, intr, init_extrinsics):
+        intr = np.ascontiguousarray(intr, np.float64)
+        lib().orc_calib_set_intrinsics(self._h, _p(intr), 1 if init_extrinsics else 0)
+
+    def accumulate(self, lam):
+        a = np.zeros(self.ni * self.ni + self.ni + 1)
+        lib().orc_calib_accumulate(self._h, C.c_double(lam), _p(a))
+        return a
+
+    def step(self, delta):
+        d = np.ascontiguousarray(delta, np.float64)
+        return float(lib().orc_calib_step(self._h, _p(d)))
+
+    def accept(self):
+        lib().orc_calib_accept(self._h)
+
+    def get(self):
+        intr = np.zeros(12); rv = np.zeros((max(self.V, 1), 3)); tv = np.zeros((max(self.V, 1), 3))
+        lib().orc_calib_get(self._h, _p(intr), _p(rv), _p(tv))
+        return intr, rv[:self.V], tv[:self.V]

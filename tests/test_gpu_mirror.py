@@ -1,0 +1,179 @@
+"""The camera_sync mirror API on the GPU, written after the reference's own GPU-relevant tests
+(test_aruco.py:203-359): same calls, same assertions, plus the batched additions and the
+distributed calibration driver with real GPU workers."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tests import _data, _oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _markers(ids):
+    from cameracalibration_amd.camera_sync.aruco import getArucosFromPaper
+
+    a = getArucosFromPaper(1)
+    return [a[i] for i in ids]
+
+
+def test_detect_aruco_like_reference():
+    """test_aruco.py:203-326."""
+    from cameracalibration_amd.camera_sync.aruco import detectAruco
+
+    gold = _data.goldens()
+    for name in ("pic_1", "pic_2"):
+        res, rejected = detectAruco(_data.load_bgr(name + ".png"))
+        for n in range(10, 16):
+            assert n in res.keys()
+        for k in res.keys():
+            assert res[k].shape == (1, 4, 2) and res[k].dtype == np.float32
+            assert np.allclose(res[k], np.array(gold[name][str(int(k))], np.float32).reshape(1, 4, 2), atol=1e-3)
+        assert isinstance(rejected, tuple) and all(r.shape == (1, 4, 2) for r in rejected)
+    # gray input gives the same result as BGR (aruco.py:246 converts first)
+    img = _data.load_bgr("pic_2.png")
+    g = _oracle.bgr2gray(img)
+    res_g, _ = detectAruco(g)
+    res_c, _ = detectAruco(img)
+    assert res_g.keys() == res_c.keys() and all(np.array_equal(res_g[k], res_c[k]) for k in res_c)
+    none, _ = detectAruco(np.full((120, 160, 3), 128, np.uint8))
+    assert none == {}
+
+
+def test_process_aruco_like_reference():
+    """test_aruco.py:329-359."""
+    from cameracalibration_amd.camera_sync.aruco import processAruco
+    from cameracalibration_amd.camera_sync.camera import Camera
+
+    cam = Camera("Logitec_A", -1, focus=0, resolution=(1280, 720))
+    frame = _data.load_bgr("pic_2.png")
+    moving = _markers([12, 13])
+    rvec, tvec, found, metrics = processAruco(_markers([10, 11, 14, 15]), moving, cam, frame, metrics=True)
+    assert metrics["PnP"]["MAE"] < 0.6 and metrics["PnP"]["RMSE"] < 0.8
+    assert rvec.shape == (3, 1) and tvec.shape == (3, 1)
+    assert np.allclose([0.00686839, -2.92023025, 1.16051479], rvec.flatten(), atol=1e-4)
+    assert np.allclose([37.15601032, -37.2392403, 580.35313275], tvec.flatten(), atol=1e-4)
+    for n in (12, 13):
+        assert n in found
+    # the moving markers lie on the sheet: their located corners are close to the printed layout (mm)
+    for m, want in zip(moving, ([0, -95, 0], [110, -95, 0])):
+        c = np.array(m.corners)
+        assert np.allclose(c.mean(axis=0), np.array(want) + [40, -40, 0], atol=6.0)
+    # camera state was updated through the low-pass filter from (0,0,0)
+    assert np.allclose(cam.world_position.coords, 0.4 * cam.world2cam.invert.apply([0.0, 0.0, 0.0]))
+
+
+def test_process_aruco_errors():
+    from cameracalibration_amd.camera_sync.aruco import PnP, processAruco
+    from cameracalibration_amd.camera_sync.camera import Camera
+    from cameracalibration_amd._hip import CamsyncError
+
+    cam = Camera("Logitec_A", -1, focus=0, resolution=(1280, 720))
+    blank = np.full((720, 1280, 3), 200, np.uint8)
+    with pytest.raises(Exception, match="Could not find any ArUco markers in the image"):
+        processAruco(_markers([10, 11]), [], cam, blank)
+    assert processAruco(_markers([10, 11]), [], cam, blank, accept_none=True) is False
+    with pytest.raises(CamsyncError):
+        PnP(np.zeros((3, 2), np.float32), np.zeros((3, 3), np.float32), cam.mtx, cam.dist)
+
+
+def test_multiple_cameras_average():
+    """aruco.py:407-470 with the same photo seen by two 'cameras': the averaged corners equal one camera's."""
+    from cameracalibration_amd.camera_sync.aruco import processAruco, processArucoFromMultipleCameras
+    from cameracalibration_amd.camera_sync.camera import Camera
+    from cameracalibration_amd.camera_sync.aruco import getArucosFromPaper
+
+    frame = _data.load_bgr("pic_2.png")
+    cams = [Camera("Logitec_A", -1, focus=0, resolution=(1280, 720)) for _ in range(2)]
+    sheet = getArucosFromPaper(1)
+    moving = {12: sheet[12], 13: sheet[13]}
+    before = {k: np.array([c.coords for c in v.corners], float) for k, v in moving.items()}
+    processArucoFromMultipleCameras(_markers([10, 11, 14, 15]), moving, cams, [frame, frame])
+    ref_cam = Camera("Logitec_A", -1, focus=0, resolution=(1280, 720))
+    _, _, located, _ = processAruco(_markers([10, 11, 14, 15]), _markers([12, 13]), ref_cam, frame, directUpdate=False)
+    for k, a in moving.items():
+        size = a.size
+        local = [[-size / 2, size / 2, 0], [size / 2, size / 2, 0], [size / 2, -size / 2, 0], [-size / 2, -size / 2, 0]]
+        world = np.array([located[k].apply(np.array(c)) for c in local])
+        got = np.array([c.coords for c in a.corners], float)
+        assert np.allclose(got, 0.4 * world + 0.6 * before[k], atol=1e-9)
+    with pytest.raises(AssertionError):
+        processArucoFromMultipleCameras([], moving, cams, [frame])
+
+
+def test_batched_additions_equal_per_frame_calls():
+    from cameracalibration_amd import synth
+    from cameracalibration_amd.camera_sync.aruco import PnP, detectAruco, detectArucoBatch, processArucoBatch
+
+    K, dist_ = _data.calibration("Logitec_robot_1920-1080_10.npz")
+    frames = np.stack([synth.v1_frame(i, K, ss=2)[0].numpy() for i in range(3)])
+    batch = detectArucoBatch(frames)
+    anchors = _markers([10, 11, 14, 15])
+    rv, tv, ok, dets, met = processArucoBatch(anchors, frames, K, dist_, getMetrics=True)
+    for b in range(3):
+        single, _ = detectAruco(frames[b])
+        assert single.keys() == batch[b][0].keys() == dets[b].keys()
+        assert all(np.array_equal(single[k], batch[b][0][k]) for k in single)
+        img, obj = [], []
+        for a in anchors:
+            if single.get(a.id) is not None:
+                obj.extend(a.getCornersAsList()); img.extend(single[a.id][0])
+        r1, t1, m1 = PnP(np.array(img, np.float32), np.array(obj, np.float32), K, dist_, True)
+        assert ok[b] and np.allclose(rv[b], r1.ravel(), atol=1e-12) and np.allclose(tv[b], t1.ravel(), atol=1e-9)
+        assert abs(met["MAE"][b] - m1["MAE"]) < 1e-9
+
+
+def test_camera_calibrate_from_points_vs_oracle():
+    from cameracalibration_amd import synth
+    from cameracalibration_amd.camera_sync.camera import Camera
+
+    obj, img, _, _ = synth.calib_views(V=9, seed=11, rational=False)
+    mtx, d = Camera.calibrateFromPoints(list(obj), [i.reshape(-1, 1, 2) for i in img], (1920, 1080))
+    rms0, K0, d0, _, _, _ = _oracle.calibrate(obj, img, (1920, 1080), False)
+    assert mtx.shape == (3, 3) and d.shape == (1, 5)
+    assert np.allclose(mtx, K0, atol=1e-5) and np.allclose(d.ravel(), d0, atol=1e-6)
+    rms, *_ = Camera.calibrateFromPoints(obj, img, (1920, 1080), returnAll=True)
+    assert abs(rms - rms0) < 1e-6  # north-star tolerance, px
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _rank_main(rank, world, port, V, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cameracalibration_amd import synth
+        from cameracalibration_amd.calibrate_dist import calibrate_distributed
+
+        obj, img, _, _ = synth.calib_views(V=V, seed=3, rational=True)
+        rms, K, d, rv, tv, span = calibrate_distributed(obj, img, (1920, 1080), rational=True, device_index=0)
+        np.savez(os.path.join(out_dir, f"r{rank}.npz"), rms=rms, K=K, d=d, rv=rv, tv=tv, span=span)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_distributed_calibration_two_ranks_on_one_gpu(tmp_path):
+    """Two processes share GPU 0 (records all-reduced over gloo): same answer as the one-GPU entry point."""
+    from cameracalibration_amd import _hip, synth
+
+    V = 31
+    mp.spawn(_rank_main, args=(2, _free_port(), V, str(tmp_path)), nprocs=2, join=True)
+    res = [np.load(tmp_path / f"r{r}.npz") for r in range(2)]
+    obj, img, _, _ = synth.calib_views(V=V, seed=3, rational=True)
+    ctx = _hip.Context(32, 32, 1)
+    rms1, K1, d1, rv1, tv1, _ = ctx.calibrate(obj, img, (1920, 1080), rational=True)
+    rms0 = _oracle.calibrate(obj, img, (1920, 1080), True)[0]
+    assert np.array_equal(res[0]["K"], res[1]["K"]) and np.array_equal(res[0]["d"], res[1]["d"])
+    assert abs(float(res[0]["rms"]) - rms1) < 1e-9 and abs(float(res[0]["rms"]) - rms0) < 1e-6
+    assert np.allclose(res[0]["K"], K1, atol=1e-5) and np.allclose(res[0]["d"], d1, atol=1e-4)
+    rv = np.concatenate([r["rv"] for r in res]); tv = np.concatenate([r["tv"] for r in res])
+    assert np.allclose(rv, rv1, atol=1e-7) and np.allclose(tv, tv1, atol=1e-6)
+    assert [tuple(r["span"]) for r in res] == [(0, 16), (16, 31)]

@@ -1,0 +1,126 @@
+"""The CPU oracle against everything the reference's own tests pin:
+P1  test_aruco.py:203-326   ids and 96 corner floats of pic_1 / pic_2       (1e-3 px)
+P2' test_aruco.py:345-346   golden corners -> golden camera pose             (1e-4)
+P3  test_referential.py     Rodrigues both directions
+Runs without a GPU."""
+import numpy as np
+import pytest
+
+from tests import _data, _oracle
+
+
+@pytest.mark.parametrize("name", ["pic_1", "pic_2"])
+def test_p1_detection_matches_reference_goldens(name):
+    img = _data.load_bgr(name + ".png")
+    ids, corners, _ = _oracle.detect(img)
+    gold = _data.goldens()[name]
+    assert sorted(int(i) for i in ids) == sorted(int(k) for k in gold)  # exactly ids 10..15
+    for i, c in zip(ids, corners):
+        assert np.allclose(c, np.array(gold[str(int(i))], np.float32).reshape(4, 2), atol=1e-3)
+
+
+def test_p2_golden_corners_give_golden_pose():
+    g = _data.goldens()
+    pose = g["pic_2_pose"]
+    K, dist = _data.calibration("Logitec_A_1280-720_0.npz")
+    anchors = pose["anchors"]
+    obj = _data.v1_anchor_points(anchors).reshape(-1, 3)
+    img = np.concatenate([np.array(g["pic_2"][str(a)], np.float32).reshape(4, 2) for a in anchors])
+    ok, rvec, tvec = _oracle.solve_pnp(obj, img, K, dist)
+    assert ok
+    assert np.allclose(rvec, pose["rvec"], atol=1e-4)
+    assert np.allclose(tvec, pose["tvec"], atol=1e-4)
+    d = np.linalg.norm(_oracle.project_points(obj, rvec, tvec, K, dist) - img, axis=1)
+    assert d.mean() < pose["mae_lt"] and np.sqrt((d ** 2).mean()) < pose["rmse_lt"]
+
+
+def test_p2_end_to_end_from_pixels():
+    """pic_2 pixels -> detection -> PnP reproduces the pose test_process_aruco expects."""
+    g = _data.goldens()["pic_2_pose"]
+    K, dist = _data.calibration("Logitec_A_1280-720_0.npz")
+    ids, corners, _ = _oracle.detect(_data.load_bgr("pic_2.png"))
+    by_id = {int(i): c for i, c in zip(ids, corners)}
+    obj = _data.v1_anchor_points(g["anchors"]).reshape(-1, 3)
+    img = np.concatenate([by_id[a] for a in g["anchors"]])
+    ok, rvec, tvec = _oracle.solve_pnp(obj, img, K, dist)
+    assert ok and np.allclose(rvec, g["rvec"], atol=1e-4) and np.allclose(tvec, g["tvec"], atol=1e-4)
+    for m in g["moving"]:
+        ok, _, tv = _oracle.ippe_square(by_id[m], 80.0, K, dist)
+        assert ok and tv[2] > 0
+
+
+def test_p3_rodrigues_known_answers():
+    r = np.array([0.1, 0.2, 0.3])
+    assert np.allclose(_oracle.rodrigues_mat2vec(_oracle.rodrigues_vec2mat(r)), r)  # test_referential.py:12-23
+    rz90 = np.array([[0.0, -1, 0], [1, 0, 0], [0, 0, 1]])
+    assert np.allclose(_oracle.rodrigues_mat2vec(rz90), [0, 0, np.pi / 2], atol=1e-4)  # :57-68
+    r = np.array([0.3, -0.5, 0.7])
+    R = _oracle.rodrigues_vec2mat(r)
+    assert np.allclose(R @ R.T, np.eye(3), atol=1e-12) and np.isclose(np.linalg.det(R), 1.0)  # :190-209
+    # angle pi branch
+    ry180 = np.diag([-1.0, 1.0, -1.0])
+    assert np.allclose(np.abs(_oracle.rodrigues_mat2vec(ry180)), [0, np.pi, 0], atol=1e-9)
+
+
+def test_rodrigues_host_mirror_agrees_with_oracle():
+    from cameracalibration_amd.camera_sync import referential as ref
+
+    rng = np.random.default_rng(5)
+    for _ in range(200):
+        r = rng.normal(size=3) * rng.choice([1e-9, 0.01, 1.0, 3.0])
+        R = ref.rodrigues_to_matrix(r)
+        assert np.allclose(R, _oracle.rodrigues_vec2mat(r), atol=1e-13)
+        assert np.allclose(ref.matrix_to_rodrigues(R), _oracle.rodrigues_mat2vec(R), atol=1e-10)
+
+
+def test_gray_and_threshold_integer_definitions():
+    """orc_bgr2gray / orc_adaptive_threshold against their textbook definitions on a small image."""
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    gray = _oracle.bgr2gray(img)
+    b, g, r = (img[..., k].astype(np.int64) for k in range(3))
+    assert np.array_equal(gray, ((b * 3735 + g * 19235 + r * 9798 + (1 << 14)) >> 15).astype(np.uint8))
+    for win in (3, 13, 23):
+        out = _oracle.adaptive_threshold(gray, win, 7.0)
+        rad = win // 2
+        pad = np.pad(gray.astype(np.int64), rad, mode="edge")  # BORDER_REPLICATE box filter
+        s = np.zeros(gray.shape, np.int64)
+        for dy in range(win):
+            for dx in range(win):
+                s += pad[dy:dy + gray.shape[0], dx:dx + gray.shape[1]]
+        mean = np.floor(s / (win * win) + 0.5)  # rounded mean (ties cannot occur exactly at .5 for odd win^2 ... kept general)
+        expect = np.where(gray.astype(np.int64) - mean <= -7, 255, 0).astype(np.uint8)
+        # the box-filter mean is rounded half-to-even by OpenCV; windows with odd area never hit a tie
+        assert np.array_equal(out, expect)
+
+
+def test_contours_tiny_cases():
+    z = np.zeros((8, 8), np.uint8)
+    assert _oracle.find_contours(z) == []
+    z[3, 3] = 255
+    c = _oracle.find_contours(z)
+    assert len(c) == 1 and c[0].tolist() == [[3, 3]]
+    z[:] = 0
+    z[2:6, 2:6] = 255
+    z[3:5, 3:5] = 0  # ring: outer border + hole border, discovery order reversed by RETR_LIST
+    c = _oracle.find_contours(z)
+    assert len(c) == 2 and sorted(len(k) for k in c) == [8, 12]
+    assert c[-1][0].tolist() == [2, 2]  # the outer border was found first, so it is listed last
+
+
+def test_dictionary_verified_ids_identify():
+    """Render each verified id at rotation 0..3 as an ideal 6x6-cell image and identify it."""
+    from cameracalibration_amd import _dict4x4_50 as d
+
+    for mid in sorted(d.VERIFIED_IDS)[:12]:
+        code = int(d.CODES[mid])
+        cells = np.zeros((6, 6), np.uint8)
+        for k in range(16):
+            if (code >> (15 - k)) & 1:
+                cells[1 + k // 4, 1 + k % 4] = 255
+        img = np.full((120, 120), 255, np.uint8)
+        img[24:96, 24:96] = np.kron(cells, np.ones((12, 12), np.uint8))
+        corners = np.array([[24, 24], [95, 24], [95, 95], [24, 95]], np.float32)
+        for rot in range(4):
+            ok, idv, r, _ = _oracle.identify(img, np.roll(corners, -rot, axis=0))
+            assert ok and idv == mid
