@@ -222,7 +222,7 @@ class Context:
         out = np.zeros(8, np.int32)
         self._check(self._lib.camsync_debug_counts(self._h, frame, _ptr(out)))
         return dict(candidates=int(out[0]), contours=int(out[1]), points=int(out[2]), markers=int(out[3]),
-                    overflow=int(out[4]), quads=int(out[5]), trace_steps=int(out[6]), max_abort_steps=int(out[7]))
+                    overflow=int(out[4]), quads=int(out[5]), long_candidates=int(out[6]), queue_head=int(out[7]))
 
     def debug_quads(self, frame=0, cap=256):
         c = np.zeros((cap, 4, 2), np.float32)

@@ -104,11 +104,18 @@ int camsync_detect_batch(camsync_ctx* ctx, const uint8_t* frames, int on_device,
                          int max_markers, int32_t* ids, float* corners, int32_t* counts,
                          int max_rejected, float* rejected, int32_t* rej_counts);
 
-/* Intermediate results of the last camsync_detect_batch chunk, for parity
- * tests: what = 0 contour candidates examined, 1 contours kept by the perimeter
- * filter, 2 quads (out: per quad 8 f32 corners, then scale, scan key, contour
- * length as f32-encoded ints are NOT used — see layout in DESIGN.md).
- * Returns the element count, or <0. */
+/* Intermediate results of the last chunk processed (parity tests and tuning, no counterpart in the
+ * reference: OpenCV does not expose them).
+ *   camsync_debug_counts   chunk-wide counters: [0] contour-start candidates, [1] contours kept by the
+ *                          perimeter filter, [2] contour points stored, [3] markers accepted, [4] overflow
+ *                          flags (0 = no scratch list overflowed), [5] quads of `frame`, [6] candidates that
+ *                          went to the long-border pass, [7] work-queue head of that pass
+ *   camsync_debug_quads    quad candidates of `frame` after approxPolyDP and the size/convexity filters,
+ *                          before duplicate removal: corners f32 [n,4,2] (clockwise), threshold scale, raster
+ *                          key of the contour start, contour length, identified id (-1 = rejected), rotation
+ *   camsync_debug_contours contours of `frame`: threshold scale, raster key of the start pixel, hole flag,
+ *                          length in points
+ * The quad/contour calls return the number of elements available (may exceed the capacity passed), or <0. */
 int camsync_debug_counts(camsync_ctx* ctx, int frame, int32_t out[8]);
 int camsync_debug_quads(camsync_ctx* ctx, int frame, int max_quads, float* corners,
                         int32_t* scale, int32_t* scan_key, int32_t* contour_len,
@@ -172,9 +179,8 @@ int camsync_calibrate(camsync_ctx* ctx, const float* obj, const float* img, int 
 /* Multi-GPU calibration building blocks (one rank per GPU, views sharded
  * contiguously).  The caller owns the LM loop (cvCalibrateCamera2Internal's
  * CvLevMarq::updateAlt state machine) and all-reduces (sum) the small record
- * between accumulate and step; cameracalibration_amd/camera_sync/
- * calibrate_dist.py is the torch.distributed (RCCL) driver, camsync_calibrate
- * the single-GPU one.
+ * between accumulate and step; cameracalibration_amd/calibrate_dist.py is the
+ * torch.distributed (RCCL) driver, camsync_calibrate the single-GPU one.
  *   camsync_calib_begin       upload this rank's views (obj f32 [V,P,3], img
  *                             f32 [V,P,2], P <= 64); flags bit0 = rational
  *   camsync_calib_focal_acc   this rank's sums for the closed-form focal
