@@ -2,19 +2,21 @@
 // of ArucoDetector.detectMarkers, fused in one pass (reference call sites:
 // camera_sync/aruco.py:246 cv.cvtColor, :256-264 detectMarkers step 1a).
 //
-// Layout: one workgroup walks a horizontal band of one frame top to bottom.
-// Each of the 256 threads owns 8 adjacent columns (2048 columns per
-// workgroup, 16 of them halo on each side).  Per row the thread reads its 24
-// BGR bytes once (coalesced), converts to luma, writes the gray row, keeps the
-// last 2*rmax+2 gray rows in an LDS ring and maintains the vertical running
-// sums of every window in registers.  The vertical sums are exchanged through
-// LDS and slid horizontally, so every input byte is fetched from HBM once
-// (plus the band/chunk halos) and the three threshold images leave as one
-// packed byte per pixel (bit s = scale s).
+// Layout: one wavefront (= one workgroup, so no workgroup barriers) walks a
+// 512-column strip of one frame top to bottom; 16 columns on each side are
+// halo, 480 produce output (1920 = 4 strips).  Each lane owns 8 adjacent
+// columns.  Per row the lane reads its 24 BGR bytes once (coalesced), converts
+// to luma with two byte dot products, writes the gray row, keeps the last
+// 2*rmax+2 gray rows in an LDS ring and maintains the vertical running sums of
+// the three windows in registers as packed 16-bit pairs.  The vertical sums
+// are exchanged through LDS and slid horizontally, so every input byte is
+// fetched from HBM once (plus the strip halos) and the three threshold images
+// leave as bit planes (one bit per pixel and scale).
 //
 // Integer-exact: luma = (3735 B + 19235 G + 9798 R + 2^14) >> 15;
 // out_s = 1  <=>  round(sum/k^2) >= src + idelta  <=>  2 sum >= (2(src+idelta)-1) k^2
-// (k^2 is odd, so the rounded mean never ties).
+//            <=>  sum >= k^2 src + ((2 idelta - 1) k^2 + 1) / 2
+// (k^2 is odd, so the rounded mean never ties and the last division is exact).
 #include "internal.h"
 
 namespace camsync {
@@ -22,8 +24,8 @@ namespace camsync {
 namespace {
 
 constexpr int PX = 8;
-constexpr int TPB = 256;
-constexpr int ROWPX = PX * TPB;  // 2048
+constexpr int TPB = 64;
+constexpr int ROWPX = PX * TPB;  // 512
 constexpr int HALO = 16;         // >= max radius, multiple of PX
 constexpr int CHUNKW = ROWPX - 2 * HALO;
 
@@ -31,37 +33,53 @@ __device__ __forceinline__ uint32_t luma(uint32_t b, uint32_t g, uint32_t r) {
     return (b * 3735u + g * 19235u + r * 9798u + 16384u) >> 15;
 }
 
+// luma of the pixel whose B,G,R are bytes 0,1,2 of p: the weights split as w = 256 wh + wl
+// (3735 = 14*256+151, 19235 = 75*256+35, 9798 = 38*256+70), each half a byte dot product.
+__device__ __forceinline__ uint32_t luma_dot(uint32_t p) {
+    const uint32_t lo = __builtin_amdgcn_udot4(p, 0x00462397u, 16384u, false);
+    const uint32_t hi = __builtin_amdgcn_udot4(p, 0x00264B0Eu, 0u, false);
+    return ((hi << 8) + lo) >> 15;
+}
+
 // Load the 8 gray values of columns xbase..xbase+7 (clamped to the image) of
 // row `row` (already clamped) of frame f, converting from BGR when C == 3.
 __device__ __forceinline__ uint2 load_gray8(const uint8_t* __restrict__ in, int C, int W, size_t rowOff,
                                             int xbase, bool aligned) {
     uint32_t g[8];
-    if (xbase >= 0 && xbase + 7 < W && aligned) {
+    if (aligned) {
+        // W is a multiple of 8 and so is xbase: a group is inside the image or entirely outside, where
+        // BORDER_REPLICATE makes all 8 values the edge pixel of the nearest inside group
+        const int xc = min(max(xbase, 0), W - 8);
+        uint2 r;
         if (C == 3) {
-            const uint2* p = reinterpret_cast<const uint2*>(in + (rowOff + (size_t)xbase) * 3);
-            uint2 a = p[0], b = p[1], c = p[2];
-            uint32_t w[6] = {a.x, a.y, b.x, b.y, c.x, c.y};
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                int o = 3 * i;
-                uint32_t bb = (w[o >> 2] >> ((o & 3) * 8)) & 255u;
-                uint32_t gg = (w[(o + 1) >> 2] >> (((o + 1) & 3) * 8)) & 255u;
-                uint32_t rr = (w[(o + 2) >> 2] >> (((o + 2) & 3) * 8)) & 255u;
-                g[i] = luma(bb, gg, rr);
-            }
+            const uint2* p = reinterpret_cast<const uint2*>(in + (rowOff + (size_t)xc) * 3);
+            const uint2 a = p[0], b = p[1], c = p[2];
+            // pixel i starts at byte 3 i of the 24 bytes a.x a.y b.x b.y c.x c.y
+            g[0] = luma_dot(a.x);
+            g[1] = luma_dot(__builtin_amdgcn_alignbyte(a.y, a.x, 3));
+            g[2] = luma_dot(__builtin_amdgcn_alignbyte(b.x, a.y, 2));
+            g[3] = luma_dot(__builtin_amdgcn_alignbyte(b.y, b.x, 1));
+            g[4] = luma_dot(b.y);
+            g[5] = luma_dot(__builtin_amdgcn_alignbyte(c.x, b.y, 3));
+            g[6] = luma_dot(__builtin_amdgcn_alignbyte(c.y, c.x, 2));
+            g[7] = luma_dot(c.y >> 8);
+            r.x = g[0] | (g[1] << 8) | (g[2] << 16) | (g[3] << 24);
+            r.y = g[4] | (g[5] << 8) | (g[6] << 16) | (g[7] << 24);
         } else {
-            return *reinterpret_cast<const uint2*>(in + rowOff + (size_t)xbase);
+            r = *reinterpret_cast<const uint2*>(in + rowOff + (size_t)xc);
         }
-    } else {
+        if (xbase < 0) r.x = r.y = (r.x & 255u) * 0x01010101u;
+        else if (xbase >= W) r.x = r.y = (r.y >> 24) * 0x01010101u;
+        return r;
+    }
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            int x = min(max(xbase + i, 0), W - 1);
-            if (C == 3) {
-                const uint8_t* p = in + (rowOff + (size_t)x) * 3;
-                g[i] = luma(p[0], p[1], p[2]);
-            } else {
-                g[i] = in[rowOff + (size_t)x];
-            }
+    for (int i = 0; i < 8; i++) {
+        int x = min(max(xbase + i, 0), W - 1);
+        if (C == 3) {
+            const uint8_t* p = in + (rowOff + (size_t)x) * 3;
+            g[i] = luma(p[0], p[1], p[2]);
+        } else {
+            g[i] = in[rowOff + (size_t)x];
         }
     }
     uint2 r;
@@ -75,8 +93,16 @@ __device__ __forceinline__ void unpack8(uint2 v, uint32_t o[8]) {
     o[4] = v.y & 255u; o[5] = (v.y >> 8) & 255u; o[6] = (v.y >> 16) & 255u; o[7] = v.y >> 24;
 }
 
+// 8 bytes -> 4 words of two 16-bit fields (pixel 2k in the low half of word k)
+__device__ __forceinline__ void widen8(uint2 v, uint32_t o[4]) {
+    o[0] = __builtin_amdgcn_perm(0u, v.x, 0x0C010C00u);
+    o[1] = __builtin_amdgcn_perm(0u, v.x, 0x0C030C02u);
+    o[2] = __builtin_amdgcn_perm(0u, v.y, 0x0C010C00u);
+    o[3] = __builtin_amdgcn_perm(0u, v.y, 0x0C030C02u);
+}
+
 // Sliding horizontal sum of radius R over the exchanged vertical sums.
-// xb points at this scale's row of u16 sums; base = PX*tid.
+// xb points at this scale's row of u16 sums; base = PX*lane.
 template <int R>
 __device__ __forceinline__ void hsum8(const uint16_t* xb, int base, uint32_t out[8]) {
     // window of pixel i covers [base+i-R, base+i+R]; gather [lo, lo+N) with lo even
@@ -102,6 +128,18 @@ __device__ __forceinline__ void hsum8(const uint16_t* xb, int base, uint32_t out
     }
 }
 
+// bit i of the result = (s[i] >= K c[i] + C), built most significant first with compare + add-with-carry
+template <int K>
+__device__ __forceinline__ uint32_t thresh_bits(const uint32_t s[8], const uint32_t c[8], int cst) {
+    uint32_t acc = 0;
+#pragma unroll
+    for (int i = 7; i >= 0; i--) {
+        const int t = (int)c[i] * K + cst;
+        acc = acc + acc + (((int)s[i] >= t) ? 1u : 0u);
+    }
+    return acc;
+}
+
 template <int R0, int R1, int R2>
 __global__ __launch_bounds__(TPB) void k_gray_thresh3(const uint8_t* __restrict__ in, int C, uint8_t* __restrict__ gray,
                                                       uint8_t* __restrict__ bin, uint32_t* __restrict__ planes, int WS, int H, int W, int bandH, int idelta) {
@@ -109,7 +147,7 @@ __global__ __launch_bounds__(TPB) void k_gray_thresh3(const uint8_t* __restrict_
     constexpr int RING = 2 * RMAX + 2;
     static_assert(R0 <= R1 && R1 <= R2 && R2 <= HALO - 1, "radii must be sorted and fit the halo");
     __shared__ __align__(16) uint8_t ring[RING][ROWPX];
-    __shared__ __align__(16) uint16_t xbuf[2][3][ROWPX];
+    __shared__ __align__(16) uint16_t xbuf[3][ROWPX + 2 * HALO];  // HALO columns of slack on both sides (edge lanes read there, unused)
 
     const int tid = threadIdx.x;
     const int f = blockIdx.z;
@@ -121,10 +159,11 @@ __global__ __launch_bounds__(TPB) void k_gray_thresh3(const uint8_t* __restrict_
     const size_t frameOff = (size_t)f * H * W;
     const bool inOut = (tid >= HALO / PX) && (tid < TPB - HALO / PX) && xbase < W;  // produces output
     const bool fullOut = inOut && (xbase + 7 < W) && aligned;
+    constexpr int K0 = (2 * R0 + 1) * (2 * R0 + 1), K1 = (2 * R1 + 1) * (2 * R1 + 1), K2 = (2 * R2 + 1) * (2 * R2 + 1);
+    const int c0 = ((2 * idelta - 1) * K0 + 1) >> 1, c1 = ((2 * idelta - 1) * K1 + 1) >> 1, c2 = ((2 * idelta - 1) * K2 + 1) >> 1;
 
-    uint32_t V0[8], V1[8], V2[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) V0[i] = V1[i] = V2[i] = 0;
+    // vertical running sums, two 16-bit fields per word (at most 23 * 255 per field)
+    uint32_t V0[4] = {0, 0, 0, 0}, V1[4] = {0, 0, 0, 0}, V2[4] = {0, 0, 0, 0};
 
     auto slot = [&](int row) { return (row + 4 * RING) % RING; };
     auto rowOffOf = [&](int row) { return frameOff + (size_t)min(max(row, 0), H - 1) * W; };
@@ -133,78 +172,65 @@ __global__ __launch_bounds__(TPB) void k_gray_thresh3(const uint8_t* __restrict_
     for (int d = -RMAX - 1; d <= RMAX - 1; d++) {
         uint2 g = load_gray8(in, C, W, rowOffOf(y0 + d), xbase, aligned);
         *reinterpret_cast<uint2*>(&ring[slot(y0 + d)][PX * tid]) = g;
-        uint32_t u[8];
-        unpack8(g, u);
+        uint32_t u[4];
+        widen8(g, u);
         if (d >= -R0 - 1 && d <= R0 - 1) {
 #pragma unroll
-            for (int i = 0; i < 8; i++) V0[i] += u[i];
+            for (int i = 0; i < 4; i++) V0[i] += u[i];
         }
         if (d >= -R1 - 1 && d <= R1 - 1) {
 #pragma unroll
-            for (int i = 0; i < 8; i++) V1[i] += u[i];
+            for (int i = 0; i < 4; i++) V1[i] += u[i];
         }
         {
 #pragma unroll
-            for (int i = 0; i < 8; i++) V2[i] += u[i];
+            for (int i = 0; i < 4; i++) V2[i] += u[i];
         }
     }
 
     uint2 nxt = load_gray8(in, C, W, rowOffOf(y0 + RMAX), xbase, aligned);
-    int buf = 0;
     for (int y = y0; y < y1; y++) {
         uint2 gin = nxt;
         if (y + 1 < y1) nxt = load_gray8(in, C, W, rowOffOf(y + 1 + RMAX), xbase, aligned);
         *reinterpret_cast<uint2*>(&ring[slot(y + RMAX)][PX * tid]) = gin;
 
-        uint32_t a[8], b[8];
+        uint32_t a[4], b[4];
         // largest window: incoming row is the one just loaded
-        unpack8(gin, a);
-        unpack8(*reinterpret_cast<const uint2*>(&ring[slot(y - R2 - 1)][PX * tid]), b);
+        widen8(gin, a);
+        widen8(*reinterpret_cast<const uint2*>(&ring[slot(y - R2 - 1)][PX * tid]), b);
 #pragma unroll
-        for (int i = 0; i < 8; i++) V2[i] += a[i] - b[i];
-        unpack8(*reinterpret_cast<const uint2*>(&ring[slot(y + R1)][PX * tid]), a);
-        unpack8(*reinterpret_cast<const uint2*>(&ring[slot(y - R1 - 1)][PX * tid]), b);
+        for (int i = 0; i < 4; i++) V2[i] = V2[i] + a[i] - b[i];
+        widen8(*reinterpret_cast<const uint2*>(&ring[slot(y + R1)][PX * tid]), a);
+        widen8(*reinterpret_cast<const uint2*>(&ring[slot(y - R1 - 1)][PX * tid]), b);
 #pragma unroll
-        for (int i = 0; i < 8; i++) V1[i] += a[i] - b[i];
-        unpack8(*reinterpret_cast<const uint2*>(&ring[slot(y + R0)][PX * tid]), a);
-        unpack8(*reinterpret_cast<const uint2*>(&ring[slot(y - R0 - 1)][PX * tid]), b);
+        for (int i = 0; i < 4; i++) V1[i] = V1[i] + a[i] - b[i];
+        widen8(*reinterpret_cast<const uint2*>(&ring[slot(y + R0)][PX * tid]), a);
+        widen8(*reinterpret_cast<const uint2*>(&ring[slot(y - R0 - 1)][PX * tid]), b);
 #pragma unroll
-        for (int i = 0; i < 8; i++) V0[i] += a[i] - b[i];
+        for (int i = 0; i < 4; i++) V0[i] = V0[i] + a[i] - b[i];
 
-        // exchange vertical sums
-        uint4 w;
-        w.x = V0[0] | (V0[1] << 16); w.y = V0[2] | (V0[3] << 16); w.z = V0[4] | (V0[5] << 16); w.w = V0[6] | (V0[7] << 16);
-        *reinterpret_cast<uint4*>(&xbuf[buf][0][PX * tid]) = w;
-        w.x = V1[0] | (V1[1] << 16); w.y = V1[2] | (V1[3] << 16); w.z = V1[4] | (V1[5] << 16); w.w = V1[6] | (V1[7] << 16);
-        *reinterpret_cast<uint4*>(&xbuf[buf][1][PX * tid]) = w;
-        w.x = V2[0] | (V2[1] << 16); w.y = V2[2] | (V2[3] << 16); w.z = V2[4] | (V2[5] << 16); w.w = V2[6] | (V2[7] << 16);
-        *reinterpret_cast<uint4*>(&xbuf[buf][2][PX * tid]) = w;
+        // exchange vertical sums (single wavefront: the barrier only orders this wave's LDS traffic)
+        __syncthreads();
+        *reinterpret_cast<uint4*>(&xbuf[0][HALO + PX * tid]) = make_uint4(V0[0], V0[1], V0[2], V0[3]);
+        *reinterpret_cast<uint4*>(&xbuf[1][HALO + PX * tid]) = make_uint4(V1[0], V1[1], V1[2], V1[3]);
+        *reinterpret_cast<uint4*>(&xbuf[2][HALO + PX * tid]) = make_uint4(V2[0], V2[1], V2[2], V2[3]);
         __syncthreads();
 
         if (inOut) {
             const uint2 cen = *reinterpret_cast<const uint2*>(&ring[slot(y)][PX * tid]);
             uint32_t c[8], s0[8], s1[8], s2[8];
             unpack8(cen, c);
-            hsum8<R0>(&xbuf[buf][0][0], PX * tid, s0);
-            hsum8<R1>(&xbuf[buf][1][0], PX * tid, s1);
-            hsum8<R2>(&xbuf[buf][2][0], PX * tid, s2);
-            constexpr int K0 = (2 * R0 + 1) * (2 * R0 + 1), K1 = (2 * R1 + 1) * (2 * R1 + 1), K2 = (2 * R2 + 1) * (2 * R2 + 1);
-            uint32_t ob[8];
-            uint32_t pm0 = 0, pm1 = 0, pm2 = 0;  // one byte per scale, bit i = pixel xbase+i
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                int t2 = 2 * ((int)c[i] + idelta) - 1;
-                const uint32_t b0 = ((int)(2 * s0[i]) >= t2 * K0) ? 1u : 0u;
-                const uint32_t b1 = ((int)(2 * s1[i]) >= t2 * K1) ? 1u : 0u;
-                const uint32_t b2 = ((int)(2 * s2[i]) >= t2 * K2) ? 1u : 0u;
-                ob[i] = b0 | (b1 << 1) | (b2 << 2);
-                pm0 |= b0 << i;
-                pm1 |= b1 << i;
-                pm2 |= b2 << i;
-            }
+            hsum8<R0>(&xbuf[0][HALO], PX * tid, s0);
+            hsum8<R1>(&xbuf[1][HALO], PX * tid, s1);
+            hsum8<R2>(&xbuf[2][HALO], PX * tid, s2);
+            // one byte per scale, bit i = pixel xbase+i
+            const uint32_t pm0 = thresh_bits<K0>(s0, c, c0), pm1 = thresh_bits<K1>(s1, c, c1), pm2 = thresh_bits<K2>(s2, c, c2);
             const size_t off = frameOff + (size_t)y * W + xbase;
             if (fullOut) {
                 if (bin) {
+                    uint32_t ob[8];
+#pragma unroll
+                    for (int i = 0; i < 8; i++) ob[i] = ((pm0 >> i) & 1u) | (((pm1 >> i) & 1u) << 1) | (((pm2 >> i) & 1u) << 2);
                     uint2 o;
                     o.x = ob[0] | (ob[1] << 8) | (ob[2] << 16) | (ob[3] << 24);
                     o.y = ob[4] | (ob[5] << 8) | (ob[6] << 16) | (ob[7] << 24);
@@ -214,7 +240,7 @@ __global__ __launch_bounds__(TPB) void k_gray_thresh3(const uint8_t* __restrict_
             } else {
                 for (int i = 0; i < 8; i++)
                     if (xbase + i < W) {
-                        if (bin) bin[off + i] = (uint8_t)ob[i];
+                        if (bin) bin[off + i] = (uint8_t)(((pm0 >> i) & 1u) | (((pm1 >> i) & 1u) << 1) | (((pm2 >> i) & 1u) << 2));
                         if (gray) gray[off + i] = (uint8_t)c[i];
                     }
             }
@@ -231,21 +257,20 @@ __global__ __launch_bounds__(TPB) void k_gray_thresh3(const uint8_t* __restrict_
             pl[planeBytes] = (uint8_t)(pm1 & keep);
             pl[2 * planeBytes] = (uint8_t)(pm2 & keep);
             if (xbase + 8 >= W) {  // last byte of the row: clear the padding bytes of its word
-                for (int b = ((xbase >> 3) & 3) + 1; b < 4; b++) {
-                    uint8_t* q = pl + (b - ((xbase >> 3) & 3));
+                for (int b2 = ((xbase >> 3) & 3) + 1; b2 < 4; b2++) {
+                    uint8_t* q = pl + (b2 - ((xbase >> 3) & 3));
                     q[0] = 0; q[planeBytes] = 0; q[2 * planeBytes] = 0;
                 }
             }
             if (y == H - 1) {  // last image row: clear the padding rows of the last block row
                 for (int yy = H; yy < plane_hb(H) * 32; yy++) {
-                    for (int b = (xbase >> 3) & 3; b < ((xbase + 8 >= W) ? 4 : ((xbase >> 3) & 3) + 1); b++) {
-                        uint8_t* q = pbase + plane_word_index(WS, xbase >> 5, yy) * 4 + b;
+                    for (int b2 = (xbase >> 3) & 3; b2 < ((xbase + 8 >= W) ? 4 : ((xbase >> 3) & 3) + 1); b2++) {
+                        uint8_t* q = pbase + plane_word_index(WS, xbase >> 5, yy) * 4 + b2;
                         q[0] = 0; q[planeBytes] = 0; q[2 * planeBytes] = 0;
                     }
                 }
             }
         }
-        buf ^= 1;
     }
 }
 
@@ -311,9 +336,10 @@ void launch_gray_thresh(const DetCfg& c, const DetBuffers& b, int B, int C, hipS
     const bool fast = c.nScales == 3 && c.radius[0] == 1 && c.radius[1] == 6 && c.radius[2] == 11;
     if (fast) {
         const int chunks = (c.W + CHUNKW - 1) / CHUNKW;
-        // enough workgroups to fill 256 CUs twice, bands no shorter than 32 rows
-        int bands = (1024 + B * chunks - 1) / (B * chunks);
-        bands = max(1, min(bands, (c.H + 31) / 32));
+        // single-wave workgroups: enough of them to fill 256 CUs (10 waves each) a few times over, bands no
+        // shorter than 64 rows (every band re-reads 2*rmax+1 rows above it to warm its running sums up)
+        int bands = (8192 + B * chunks - 1) / (B * chunks);
+        bands = max(1, min(bands, (c.H + 63) / 64));
         int bandH = (c.H + bands - 1) / bands;
         bands = (c.H + bandH - 1) / bandH;
         dim3 grid(chunks, bands, B);
