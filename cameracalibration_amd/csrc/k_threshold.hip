@@ -148,6 +148,9 @@ __global__ __launch_bounds__(TPB) void k_gray_thresh3(const uint8_t* __restrict_
     static_assert(R0 <= R1 && R1 <= R2 && R2 <= HALO - 1, "radii must be sorted and fit the halo");
     __shared__ __align__(16) uint8_t ring[RING][ROWPX];
     __shared__ __align__(16) uint16_t xbuf[3][ROWPX + 2 * HALO];  // HALO columns of slack on both sides (edge lanes read there, unused)
+    // 16 rows of plane bits of this strip, laid out like the planes (scale, block, row): flushed as 64-byte pieces
+    constexpr int NBLK = CHUNKW / 32;
+    __shared__ __align__(16) uint32_t stage[3][NBLK][16];
 
     const int tid = threadIdx.x;
     const int f = blockIdx.z;
@@ -164,6 +167,25 @@ __global__ __launch_bounds__(TPB) void k_gray_thresh3(const uint8_t* __restrict_
 
     // vertical running sums, two 16-bit fields per word (at most 23 * 255 per field)
     uint32_t V0[4] = {0, 0, 0, 0}, V1[4] = {0, 0, 0, 0}, V2[4] = {0, 0, 0, 0};
+
+    for (int i = tid; i < 3 * NBLK * 16; i += TPB) (&stage[0][0][0])[i] = 0u;
+    const size_t perPlane = plane_words(H, WS);
+    uint32_t* const fplanes = planes + (size_t)f * 3 * perPlane;
+    const int bx0 = cx0 >> 5;  // first plane block of this strip (CHUNKW is a multiple of 32)
+    // write rows [16 hb, 16 hb + 16) of the strip's blocks to the three planes
+    auto flush = [&](int hb) {
+        __syncthreads();
+        for (int i = tid; i < 3 * NBLK * 4; i += TPB) {
+            const int sc = i / (NBLK * 4), rem = i - sc * (NBLK * 4), blk = rem >> 2, q = rem & 3;
+            if (bx0 + blk < WS) {
+                const uint4 v = *reinterpret_cast<const uint4*>(&stage[sc][blk][q * 4]);
+                uint32_t* dst = fplanes + (size_t)sc * perPlane + ((size_t)(hb >> 1) * WS + bx0 + blk) * 32 + (hb & 1) * 16 + q * 4;
+                *reinterpret_cast<uint4*>(dst) = v;
+            }
+        }
+        __syncthreads();
+    };
+    uint8_t* const myStage = reinterpret_cast<uint8_t*>(&stage[0][0][0]) + (((tid - HALO / PX) >> 2) * 16) * 4 + ((tid - HALO / PX) & 3);
 
     auto slot = [&](int row) { return (row + 4 * RING) % RING; };
     auto rowOffOf = [&](int row) { return frameOff + (size_t)min(max(row, 0), H - 1) * W; };
@@ -249,27 +271,22 @@ __global__ __launch_bounds__(TPB) void k_gray_thresh3(const uint8_t* __restrict_
             if (y == 0 || y == H - 1) keep = 0;
             if (xbase == 0) keep &= 0xFEu;
             if (xbase + 7 >= W - 1) keep &= ~(1u << ((W - 1) - xbase)) & ((W - xbase) >= 8 ? 0xFFu : ((1u << (W - xbase)) - 1u));
-            // block-linear layout (internal.h): byte b of word (xw, y)
-            const size_t planeBytes = plane_words(H, WS) * 4;
-            uint8_t* pbase = reinterpret_cast<uint8_t*>(planes) + (size_t)f * 3 * planeBytes;
-            uint8_t* pl = pbase + plane_word_index(WS, xbase >> 5, y) * 4 + ((xbase >> 3) & 3);
-            pl[0] = (uint8_t)(pm0 & keep);
-            pl[planeBytes] = (uint8_t)(pm1 & keep);
-            pl[2 * planeBytes] = (uint8_t)(pm2 & keep);
-            if (xbase + 8 >= W) {  // last byte of the row: clear the padding bytes of its word
-                for (int b2 = ((xbase >> 3) & 3) + 1; b2 < 4; b2++) {
-                    uint8_t* q = pl + (b2 - ((xbase >> 3) & 3));
-                    q[0] = 0; q[planeBytes] = 0; q[2 * planeBytes] = 0;
-                }
+            // stage this row's three bytes; bytes of columns >= W are never written and stay zero
+            uint8_t* q = myStage + (y & 15) * 4;
+            q[0] = (uint8_t)(pm0 & keep);
+            q[NBLK * 64] = (uint8_t)(pm1 & keep);
+            q[2 * NBLK * 64] = (uint8_t)(pm2 & keep);
+        }
+        if ((y & 15) == 15) flush(y >> 4);
+    }
+    // the band that ends the image also writes the zero rows that pad the last block row
+    if (y1 == H) {
+        for (int yy = H; yy < plane_hb(H) * 32; yy++) {
+            if (inOut) {
+                uint8_t* q = myStage + (yy & 15) * 4;
+                q[0] = 0; q[NBLK * 64] = 0; q[2 * NBLK * 64] = 0;
             }
-            if (y == H - 1) {  // last image row: clear the padding rows of the last block row
-                for (int yy = H; yy < plane_hb(H) * 32; yy++) {
-                    for (int b2 = (xbase >> 3) & 3; b2 < ((xbase + 8 >= W) ? 4 : ((xbase >> 3) & 3) + 1); b2++) {
-                        uint8_t* q = pbase + plane_word_index(WS, xbase >> 5, yy) * 4 + b2;
-                        q[0] = 0; q[planeBytes] = 0; q[2 * planeBytes] = 0;
-                    }
-                }
-            }
+            if ((yy & 15) == 15) flush(yy >> 4);
         }
     }
 }
@@ -340,7 +357,7 @@ void launch_gray_thresh(const DetCfg& c, const DetBuffers& b, int B, int C, hipS
         // shorter than 64 rows (every band re-reads 2*rmax+1 rows above it to warm its running sums up)
         int bands = (8192 + B * chunks - 1) / (B * chunks);
         bands = max(1, min(bands, (c.H + 63) / 64));
-        int bandH = (c.H + bands - 1) / bands;
+        int bandH = (((c.H + bands - 1) / bands) + 31) & ~31;  // whole plane blocks per band
         bands = (c.H + bandH - 1) / bandH;
         dim3 grid(chunks, bands, B);
         hipLaunchKernelGGL((k_gray_thresh3<1, 6, 11>), grid, dim3(TPB), 0, st, b.in, C, b.gray, b.bin, b.planes, c.WS, c.H, c.W, bandH, c.idelta);
