@@ -189,6 +189,9 @@ int enqueue_detect(camsync_ctx* c, const uint8_t* d_in, int B, int H, int W, int
     DetCfg cfg = make_cfg(c, H, W);
     int rcp = ensure_planes(c, cfg.nScales);
     if (rcp) return rcp;
+    if (cfg.maxPerim > 2 * kCkMax * kCkStride - 4)
+        return fail(c, CAMSYNC_E_ARG, "maxMarkerPerimeterRate gives contours of up to %d points, the border follower handles %d",
+                    cfg.maxPerim, 2 * kCkMax * kCkStride - 4);
     DetBuffers b = c->buf;
     b.in = d_in;
     b.bin = nullptr;
@@ -239,7 +242,7 @@ int check_overflow(camsync_ctx* c) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (h.overflow)
         return fail(c, CAMSYNC_E_CAPACITY,
-                    "detection scratch overflow (mask 0x%x: 1 starts, 2 contours, 4 points, 8 quads, 32 markers); "
+                    "detection scratch overflow (mask 0x%x: 1 starts, 2 contours, 4 points, 8 quads, 32 markers, 64 store tasks); "
                     "candidates %u contours %u points %u",
                     h.overflow, h.nCand, h.nContours, h.nPool);
     return CAMSYNC_OK;
@@ -252,6 +255,7 @@ int check_frame_args(camsync_ctx* c, const void* frames, int B, int H, int W, in
     if (H > c->maxH || W > c->maxW || H < 32 || W < 32)
         return fail(c, CAMSYNC_E_ARG, "frame %dx%d outside the context's range (32..%d x 32..%d)", H, W, c->maxH, c->maxW);
     if (W % 8) return fail(c, CAMSYNC_E_ARG, "frame width must be a multiple of 8 (got %d)", W);
+    if (H > 4095 || W > 4095) return fail(c, CAMSYNC_E_ARG, "frames larger than 4095 pixels a side are not supported");
     return CAMSYNC_OK;
 }
 
@@ -340,6 +344,9 @@ int camsync_create(camsync_ctx** out, int device, int max_h, int max_w, int max_
     HIPCHK(c, dalloc(&b.contours, b.contourCap));
     b.poolCap = (unsigned)std::min<size_t>(B * (size_t)262144, 0x7FFFFFFFu);
     HIPCHK(c, dalloc(&b.pool, b.poolCap));
+    b.taskCap = (unsigned)std::min<size_t>((size_t)b.contourCap * 2 + b.poolCap / kCkStride + 64, 0x7FFFFFFFu);
+    HIPCHK(c, dalloc(&b.tasks, b.taskCap));
+    HIPCHK(c, dalloc(&b.ckpt, (size_t)kTraceWaves * 32 * 2 * kCkMax));
     HIPCHK(c, dalloc(&b.quads, B * kQuadCap));
     HIPCHK(c, dalloc(&b.qcount, B));
     HIPCHK(c, dalloc(&b.counters, 1));
@@ -374,7 +381,7 @@ void camsync_destroy(camsync_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DetBuffers& b = c->buf;
-    void* ptrs[] = {c->d_in, c->d_bin, b.planes, b.gray, b.cand, b.candLong, b.contours, b.pool, b.quads, b.qcount, b.counters, b.markers,
+    void* ptrs[] = {c->d_in, c->d_bin, b.planes, b.gray, b.cand, b.candLong, b.contours, b.pool, b.tasks, b.ckpt, b.quads, b.qcount, b.counters, b.markers,
                     b.outIds, b.outCorners, b.rawCorners, b.outCounts, b.outRejected, b.outRejCounts, c->d_dict, c->d_expTab,
                     c->d_obj, c->d_img, c->d_npts, c->d_K, c->d_dist, c->d_rvec, c->d_tvec, c->d_mae, c->d_rmse, c->d_ok,
                     c->d_anchorIds, c->d_anchorObj, c->d_calObj, c->d_calImg, c->cal.intr, c->cal.ext, c->cal.intrTrial,

@@ -76,6 +76,19 @@ struct MarkerRec {      // accepted marker, compact list for sub-pixel refinemen
     uint32_t slot;      // index in the frame's output
 };
 
+// One piece of an accepted contour for the store pass: follow the border from `state` for `count` points
+// and write them at pool[dst...].  state = x | y << 12 | s << 24 where s is the direction (0..7) from the
+// pixel to its predecessor on the border; s = 8 + hole asks for the initial search of a fresh start.
+struct StoreTask {
+    uint32_t plane;  // frame * nScales + scale
+    uint32_t state;
+    uint32_t dst;
+    uint32_t count;
+};
+constexpr int kTraceWaves = 256 * 10;  // persistent single-wave workgroups of the long-border kernels
+constexpr int kCkStride = 256;         // a checkpoint (and a store task) every this many points
+constexpr int kCkMax = 32;             // checkpoints per direction: covers borders up to 2 * 32 * 256 points
+
 struct Counters {
     unsigned int nCand;
     unsigned int nContours;
@@ -85,6 +98,8 @@ struct Counters {
     unsigned int nLong;     // candidates handed from the short-trace pass to the long-trace pass
     unsigned int qDecide;   // work-queue heads of the long-border kernels (lanes fetch their next border here)
     unsigned int qStore;
+    unsigned int nTasks;    // store tasks appended by the decide passes
+    unsigned int pad[3];
 };
 
 struct DetBuffers {
@@ -99,6 +114,9 @@ struct DetBuffers {
     unsigned int contourCap;
     uint32_t* pool;
     unsigned int poolCap;
+    StoreTask* tasks;
+    unsigned int taskCap;
+    uint32_t* ckpt;      // [kTraceWaves][32 pairs][2 directions][kCkMax] checkpoint states of borders in flight
     QuadRec* quads;      // [B,kQuadCap]
     int* qcount;         // [B]
     Counters* counters;

@@ -327,19 +327,20 @@ __device__ int probe_border(const uint32_t* __restrict__ plane, int WS, int W, i
     }
 }
 
-__device__ __forceinline__ void emit_contour(uint64_t c, int len, ContourRec* __restrict__ contours,
-                                             unsigned int contourCap, unsigned int poolCap, Counters* __restrict__ ctr) {
+// Reserve pool space and a contour record; returns the pool offset, or ~0u when a list is full.
+__device__ __forceinline__ unsigned int emit_contour(uint64_t c, int len, ContourRec* __restrict__ contours,
+                                                     unsigned int contourCap, unsigned int poolCap, Counters* __restrict__ ctr) {
     const uint32_t pos = (uint32_t)(c & 0xFFFFFFFFull);
     const bool hole = (c >> 39) & 1u;
     const unsigned int off = atomicAdd(&ctr->nPool, (unsigned int)len);
     if (off + (unsigned int)len > poolCap) {
         atomicOr(&ctr->overflow, 4u);
-        return;
+        return ~0u;
     }
     const unsigned int slot = atomicAdd(&ctr->nContours, 1u);
     if (slot >= contourCap) {
         atomicOr(&ctr->overflow, 2u);
-        return;
+        return ~0u;
     }
     ContourRec r;
     r.frame = (uint32_t)(c >> 40);
@@ -350,6 +351,19 @@ __device__ __forceinline__ void emit_contour(uint64_t c, int len, ContourRec* __
     r.hole = hole ? 1 : 0;
     r.scanKey = pos + (hole ? 1u : 0u);
     contours[slot] = r;
+    return off;
+}
+
+__device__ __forceinline__ uint32_t pack_state(int x, int y, int sdir) { return (uint32_t)x | ((uint32_t)y << 12) | ((uint32_t)sdir << 24); }
+
+// Append `n` store tasks; returns the first slot or ~0u.
+__device__ __forceinline__ unsigned int reserve_tasks(unsigned int n, unsigned int taskCap, Counters* __restrict__ ctr) {
+    const unsigned int t = atomicAdd(&ctr->nTasks, n);
+    if (t + n > taskCap) {
+        atomicOr(&ctr->overflow, 64u);
+        return ~0u;
+    }
+    return t;
 }
 
 constexpr int kShortBudget = 48;
@@ -357,7 +371,8 @@ constexpr int kShortBudget = 48;
 __global__ __launch_bounds__(256) void k_trace_short(const uint32_t* __restrict__ planes, DetCfg cfg,
                                                      const uint64_t* __restrict__ cand, unsigned int candCap,
                                                      uint64_t* __restrict__ candLong, ContourRec* __restrict__ contours,
-                                                     unsigned int contourCap, unsigned int poolCap, Counters* __restrict__ ctr) {
+                                                     unsigned int contourCap, unsigned int poolCap,
+                                                     StoreTask* __restrict__ tasks, unsigned int taskCap, Counters* __restrict__ ctr) {
     const unsigned int n = min(ctr->nCand, candCap);
     const int H = cfg.H, W = cfg.W, WS = cfg.WS, S = cfg.nScales;
     const size_t perPlane = plane_words(H, WS);
@@ -376,7 +391,20 @@ __global__ __launch_bounds__(256) void k_trace_short(const uint32_t* __restrict_
             const uint32_t* plane = planes + ((size_t)f * S + sc) * perPlane;
             res = probe_border(plane, WS, W, pos % W, pos / W, hole, kShortBudget);
         }
-        if (res >= cfg.minPerim && res <= cfg.maxPerim) emit_contour(c, res, contours, contourCap, poolCap, ctr);
+        if (res >= cfg.minPerim && res <= cfg.maxPerim) {
+            // a border this short is one store task from its fresh start
+            const unsigned int off = emit_contour(c, res, contours, contourCap, poolCap, ctr);
+            const unsigned int t = off != ~0u ? reserve_tasks(1, taskCap, ctr) : ~0u;
+            if (t != ~0u) {
+                const uint32_t pos = (uint32_t)(c & 0xFFFFFFFFull);
+                StoreTask k;
+                k.plane = (uint32_t)(c >> 40) * S + (uint32_t)((c >> 36) & 7u);
+                k.state = pack_state(pos % W, pos / W, 8 + (int)((c >> 39) & 1u));
+                k.dst = off;
+                k.count = (uint32_t)res;
+                tasks[t] = k;
+            }
+        }
         const bool undecided = res == -1;
         const unsigned long long bal = __ballot(undecided);
         if (bal) {
@@ -394,13 +422,25 @@ __global__ __launch_bounds__(256) void k_trace_short(const uint32_t* __restrict_
 }
 
 // ---- long borders -------------------------------------------------------------------------------
-// Every lane follows one border inside a private LDS window of its bit plane: 2 x 2 half-blocks
-// (32 pixels x 16 rows, 64 bytes each) = 64 columns x 32 rows, addressed toroidally (row y & 31,
-// word (x >> 5) & 1), so shifting the window by one half-block only loads the half-blocks that are new.
+// Border following is a walk on states (pixel, direction to the predecessor): the successor T(P, s) is
+// found by sweeping counter-clockwise from s + 1 to the first foreground neighbour d, giving (P + d, d + 4);
+// the predecessor is found by the same sweep run clockwise.  T is a bijection, a border is one of its cycles,
+// and OpenCV's contour is the list of pixels along the cycle from the start state.
+//
+// Decide pass: two lanes share a border.  One applies T from the start state, the other T^-1, in lock-step,
+// until they hold the same state (the cycle has been covered: length = sum of the two counts) or one of
+// them meets a crack with a smaller raster key (not the canonical start) or the length bound is exceeded.
+// That halves the longest dependent chain.  Both leave a checkpoint state every kCkStride points.
+//
+// Store pass: an accepted border is cut at the checkpoints into independent tasks of at most kCkStride
+// points (StoreTask), so writing the points of a long border is spread over many lanes.
+//
+// Both kernels are persistent; every lane follows its border inside a private LDS window of its bit plane:
+// 2 x 2 half-blocks (32 pixels x 16 rows, 64 bytes each) = 64 columns x 32 rows, addressed toroidally (row
+// y & 31, word (x >> 5) & 1), so shifting the window by one half-block only loads the half-blocks that are new.
 // A step then costs three LDS reads instead of dependent trips to L2/HBM, and the global traffic is whole
 // 64-byte pieces that are fully used.  When any lane of the wave is about to leave its window every lane
-// re-centres (lanes whose window does not move load nothing), which keeps the wave convergent.
-// Lanes that finish fetch their next border from a queue, so a wave stays busy until the queue is empty.
+// close to its edge re-centres, which keeps the wave convergent.  Lanes that finish fetch new work from a queue.
 struct TileWin {
     int gx, gy;  // window origin in half-block units: columns [32 gx, 32 gx + 64), rows [16 gy, 16 gy + 32)
     bool valid;
@@ -460,63 +500,63 @@ struct TileWin {
 __device__ __forceinline__ int fast_dx(int d) { return (int)((0x901Au >> (2 * d)) & 3u) - 1; }
 __device__ __forceinline__ int fast_dy(int d) { return (int)((0xA901u >> (2 * d)) & 3u) - 1; }
 
-// STORE = false: decide the long candidates (canonical start? length within bounds?) and reserve pool space.
-// STORE = true : write the points of the accepted contours.
-template <bool STORE>
-__global__ __launch_bounds__(64) void k_trace_tile(const uint32_t* __restrict__ planes, DetCfg cfg,
-                                                   const uint64_t* __restrict__ candLong, unsigned int candCap,
-                                                   ContourRec* __restrict__ contours, unsigned int contourCap,
-                                                   uint32_t* __restrict__ pool, unsigned int poolCap,
-                                                   Counters* __restrict__ ctr) {
+// the initial clockwise search of a fresh start (s_end - 1, s_end - 2, ...): direction of the neighbour the
+// border closes through, or -1 for a single pixel.  Rotated so that bit j is direction s_end + j, the first
+// hit clockwise is the highest of bits 1..7.
+__device__ __forceinline__ int fresh_dir(uint32_t m, bool isHole) {
+    const int s_end = isHole ? 0 : 4;
+    const uint32_t r = ((m >> s_end) | (m << (8 - s_end))) & 0xFEu;
+    return r ? ((s_end + 31 - __clz(r)) & 7) : -1;
+}
+
+// the lane's partner in its pair (lane ^ 1)
+__device__ __forceinline__ uint32_t from_partner(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
+}
+
+// Decide the long candidates (canonical start? length within bounds?), reserve pool space and cut the accepted
+// borders into store tasks.  Lanes 2p (forward) and 2p + 1 (backward) work on the same candidate.
+__global__ __launch_bounds__(64) void k_trace_decide(const uint32_t* __restrict__ planes, DetCfg cfg,
+                                                     const uint64_t* __restrict__ candLong, unsigned int candCap,
+                                                     ContourRec* __restrict__ contours, unsigned int contourCap,
+                                                     unsigned int poolCap, StoreTask* __restrict__ tasks, unsigned int taskCap,
+                                                     uint32_t* __restrict__ ckpt, Counters* __restrict__ ctr) {
     __shared__ __align__(8) uint32_t tile[32 * 2 * 64];
     const int lane = threadIdx.x;
-    const unsigned int n = STORE ? min(ctr->nContours, contourCap) : min(ctr->nLong, candCap);
-    unsigned int* qhead = STORE ? &ctr->qStore : &ctr->qDecide;
+    const bool bw = lane & 1;
+    const unsigned int n = min(ctr->nLong, candCap);
     const int H = cfg.H, W = cfg.W, WS = cfg.WS, S = cfg.nScales;
     const size_t perPlane = plane_words(H, WS);
+    uint32_t* const myCk = ckpt + (((size_t)blockIdx.x * 32 + (lane >> 1)) * 2 + (bw ? 1 : 0)) * kCkMax;
 
     bool active = false, exhausted = false, fresh = false, isHole = false;
     uint64_t c = 0;
-    int limit = 0, count = 0, startKey = 0;
-    int x0 = 1, y0 = 1, x1 = 1, y1 = 1, cx = 1, cy = 1, s = 0;
-    uint32_t* out = nullptr;
+    int count = 0, startKey = 0, cx = 1, cy = 1, s = 0;
+    uint32_t prevState = 0, state0 = 0;  // last completed state of this lane; the start state
     const uint32_t* plane = planes;
     TileWin win;
     win.gx = win.gy = 0;
     win.valid = false;
 
     for (;;) {
-        // ---- idle lanes fetch their next border (the queue hands out every index below n exactly once) ----
+        // ---- idle pairs fetch their next candidate (the queue hands out every index below n exactly once) ----
         const bool need = !active && !exhausted;
-        const unsigned long long bal = __ballot(need);
+        const unsigned long long bal = __ballot(need) & 0x5555555555555555ull;  // one bit per pair
         if (bal) {
             const int leader = __ffsll((long long)bal) - 1;
             unsigned int qb = 0;
-            if (lane == leader) qb = atomicAdd(qhead, (unsigned int)__popcll(bal));
+            if (lane == leader) qb = atomicAdd(&ctr->qDecide, (unsigned int)__popcll(bal));
             qb = __shfl(qb, leader, 64);
             if (need) {
-                const unsigned int i = qb + (unsigned int)__popcll(bal & ((1ull << lane) - 1ull));
+                const unsigned int i = qb + (unsigned int)__popcll(bal & ((1ull << (lane & ~1)) - 1ull));
                 if (i < n) {
-                    if (STORE) {
-                        const ContourRec r = contours[i];
-                        plane = planes + ((size_t)r.frame * S + r.scale) * perPlane;
-                        x0 = (int)(r.pos % W);
-                        y0 = (int)(r.pos / W);
-                        isHole = r.hole != 0;
-                        limit = (int)r.len;
-                        out = pool + r.off;
-                    } else {
-                        c = candLong[i];
-                        const uint32_t pos = (uint32_t)(c & 0xFFFFFFFFull);
-                        plane = planes + ((size_t)(uint32_t)(c >> 40) * S + (int)((c >> 36) & 7u)) * perPlane;
-                        x0 = (int)(pos % W);
-                        y0 = (int)(pos / W);
-                        isHole = (c >> 39) & 1u;
-                        limit = cfg.maxPerim + 1;  // one more point than allowed shows the border is too long
-                    }
-                    cx = x0;
-                    cy = y0;
-                    startKey = y0 * W + x0;
+                    c = candLong[i];
+                    const uint32_t pos = (uint32_t)(c & 0xFFFFFFFFull);
+                    plane = planes + ((size_t)(uint32_t)(c >> 40) * S + (int)((c >> 36) & 7u)) * perPlane;
+                    cx = (int)(pos % W);
+                    cy = (int)(pos / W);
+                    isHole = (c >> 39) & 1u;
+                    startKey = cy * W + cx;
                     count = 0;
                     win.valid = false;
                     active = true;
@@ -529,53 +569,169 @@ __global__ __launch_bounds__(64) void k_trace_tile(const uint32_t* __restrict__ 
         if (!__any(active)) break;
 
         // ---- keep every active lane's window around its pixel ----
-        // (a re-centred window leaves >= 16 columns / 8 rows of margin; when one lane must move, every lane
-        // that is close to its edge moves too, so the wave pays the load latency once per several steps)
         if (__any(active && !win.covers(cx, cy))) {
             if (active && win.near_edge(cx, cy)) win.recentre(plane, WS, H, cx, cy, tile, lane);
         }
 
+        // res: -1 keep going, 0 drop, > 0 the border closed with that many points
+        int res = -1;
+        uint32_t newState = 0;
+        bool abort = false;
         if (active) {
             const uint32_t m = win.mask(tile, lane, cx, cy);
-            int res = -1;  // -1 keep going, 0 drop, >0 closed with that many points
             if (fresh) {
-                // initial clockwise search (s_end-1, s_end-2, ...) for the neighbour the border closes through:
-                // rotate so that bit j is direction s_end + j, the first hit clockwise is the highest of bits 1..7
+                // both lanes start from the start state (P0, s0); the backward lane first steps to P0 + s0
                 fresh = false;
-                const int s_end = isHole ? 0 : 4;
-                const uint32_t r = ((m >> s_end) | (m << (8 - s_end))) & 0xFEu;
-                s = r ? ((s_end + 31 - __clz(r)) & 7) : s_end;
-                x1 = x0 + fast_dx(s);
-                y1 = y0 + fast_dy(s);
-                if (!r) {  // single pixel (never reaches these lists; kept for completeness)
-                    if (STORE) out[0] = (uint32_t)x0 | ((uint32_t)y0 << 16);
-                    res = 1;
+                const int s0 = fresh_dir(m, isHole);  // never -1 here: single pixels end in the short pass
+                s = s0 < 0 ? 0 : s0;
+                state0 = prevState = pack_state(cx, cy, s);
+                if (bw) {
+                    cx += fast_dx(s);
+                    cy += fast_dy(s);
+                    s ^= 4;  // now: direction towards the pixel we came from, the forward successor
                 }
-            }
-            if (res < 0) {
+                newState = state0;
+            } else if (!bw) {
+                // forward: from (P, s) sweep counter-clockwise from s + 1
                 const uint32_t rot = ((m >> (s + 1)) | (m << (7 - s))) & 0xFFu;  // bit j <-> direction s+1+j
                 const int k = __ffs(rot);  // 1..8: m always holds the neighbour we came from
-                const int sn = (s + k) & 7;
-                if (!STORE && (!isHole || s + k >= 9) && cy * W + cx < startKey) {
-                    res = 0;  // a crack of this border has a smaller raster key: not the canonical start
-                } else {
-                    if (STORE) out[count] = (uint32_t)cx | ((uint32_t)cy << 16);
-                    count++;
-                    const int nx = cx + fast_dx(sn), ny = cy + fast_dy(sn);
-                    if (nx == x0 && ny == y0 && cx == x1 && cy == y1) {
-                        res = count;
-                    } else if (count >= limit) {
-                        res = 0;
-                    } else {
-                        cx = nx;
-                        cy = ny;
-                        s = sn ^ 4;
+                const int d = (s + k) & 7;
+                if ((!isHole || s + k >= 9) && cy * W + cx < startKey) abort = true;  // smaller key: not canonical
+                if ((count & (kCkStride - 1)) == 0 && count) myCk[min(count / kCkStride, kCkMax - 1)] = pack_state(cx, cy, s);
+                count++;
+                cx += fast_dx(d);
+                cy += fast_dy(d);
+                s = d ^ 4;
+                newState = pack_state(cx, cy, s);
+            } else {
+                // backward: at pixel P whose forward successor lies in direction s; its predecessor is the first
+                // foreground neighbour clockwise from s - 1.  Bit-reverse the mask so clockwise = increasing bits.
+                const uint32_t mr = __brev(m) >> 24;  // bit b <-> direction 7 - b
+                const int b0 = (8 - s) & 7;           // bit of direction s - 1
+                const uint32_t rot = ((mr >> b0) | (mr << (8 - b0))) & 0xFFu;
+                const int j = __ffs(rot) - 1;         // zeros swept: directions s-1 ... s-j
+                const int p = (s - 1 - j) & 7;        // predecessor direction
+                if ((!isHole || (s >= 1 && s <= j)) && cy * W + cx < startKey) abort = true;
+                count++;
+                newState = pack_state(cx, cy, p);     // the completed state B_count
+                if ((count & (kCkStride - 1)) == 0) myCk[min(count / kCkStride, kCkMax - 1)] = newState;
+                cx += fast_dx(p);
+                cy += fast_dy(p);
+                s = p ^ 4;
+            }
+        }
+        // ---- the pair compares notes (both lanes of a pair are active or idle together) ----
+        const uint32_t pNew = from_partner(newState | (abort ? 0x80000000u : 0u));
+        const uint32_t pOld = from_partner(prevState);
+        if (active && count) {
+            const bool anyAbort = abort || (pNew >> 31);
+            const uint32_t pn = pNew & 0x7FFFFFFFu;
+            int total = -1;
+            if (pn == newState) total = 2 * count;                                   // met: every state counted once
+            else if (bw ? (pn == prevState) : (newState == pOld)) total = 2 * count - 1;  // crossed: one pixel counted twice
+            if (anyAbort) res = 0;
+            else if (total > 0) res = total;
+            else if (2 * count - 1 > cfg.maxPerim) res = 0;  // more points than allowed whatever happens next
+            if (total > cfg.maxPerim) res = 0;
+        }
+        if (active) prevState = bw ? newState : newState;
+        if (res >= 0) {
+            active = false;
+            if (res >= cfg.minPerim && res <= cfg.maxPerim) {
+                // forward lane reserves the space, both lanes cut their half into tasks
+                unsigned int off = ~0u;
+                if (!bw) off = emit_contour(c, res, contours, contourCap, poolCap, ctr);
+                off = __shfl(off, lane & ~1, 64);
+                const unsigned int nt = (unsigned int)((count + kCkStride - 1) / kCkStride);
+                const unsigned int t0 = off != ~0u ? reserve_tasks(nt, taskCap, ctr) : ~0u;
+                if (t0 != ~0u) {
+                    const uint32_t planeIdx = (uint32_t)(c >> 40) * S + (uint32_t)((c >> 36) & 7u);
+                    for (unsigned int t = 0; t < nt; t++) {
+                        StoreTask k;
+                        k.plane = planeIdx;
+                        if (!bw) {
+                            // points [t*stride, min((t+1)*stride, count)) from the start or a checkpoint
+                            k.state = t == 0 ? state0 : myCk[t];
+                            k.dst = off + t * kCkStride;
+                            k.count = min((unsigned int)kCkStride, (unsigned int)count - t * kCkStride);
+                        } else {
+                            // the backward lane's states B_1..B_count are points res-1 ... res-count; piece t
+                            // starts at B_e, e = min((t+1)*stride, count), and runs forward for e - t*stride points
+                            const unsigned int e = min((t + 1) * (unsigned int)kCkStride, (unsigned int)count);
+                            k.state = e == (unsigned int)count ? prevState : myCk[t + 1];
+                            k.dst = off + (unsigned int)res - e;
+                            k.count = e - t * kCkStride;
+                        }
+                        tasks[t0 + t] = k;
                     }
                 }
             }
-            if (res >= 0) {
+        }
+    }
+}
+
+// Write the points of the accepted borders: one lane per store task.
+__global__ __launch_bounds__(64) void k_trace_store(const uint32_t* __restrict__ planes, DetCfg cfg,
+                                                    const StoreTask* __restrict__ tasks, unsigned int taskCap,
+                                                    uint32_t* __restrict__ pool, Counters* __restrict__ ctr) {
+    __shared__ __align__(8) uint32_t tile[32 * 2 * 64];
+    const int lane = threadIdx.x;
+    const unsigned int n = min(ctr->nTasks, taskCap);
+    const int H = cfg.H, WS = cfg.WS;
+    const size_t perPlane = plane_words(H, WS);
+
+    bool active = false, exhausted = false;
+    int left = 0, cx = 1, cy = 1, s = 0;
+    uint32_t* out = nullptr;
+    const uint32_t* plane = planes;
+    TileWin win;
+    win.gx = win.gy = 0;
+    win.valid = false;
+
+    for (;;) {
+        const bool need = !active && !exhausted;
+        const unsigned long long bal = __ballot(need);
+        if (bal) {
+            const int leader = __ffsll((long long)bal) - 1;
+            unsigned int qb = 0;
+            if (lane == leader) qb = atomicAdd(&ctr->qStore, (unsigned int)__popcll(bal));
+            qb = __shfl(qb, leader, 64);
+            if (need) {
+                const unsigned int i = qb + (unsigned int)__popcll(bal & ((1ull << lane) - 1ull));
+                if (i < n) {
+                    const StoreTask k = tasks[i];
+                    plane = planes + (size_t)k.plane * perPlane;
+                    cx = (int)(k.state & 0xFFFu);
+                    cy = (int)((k.state >> 12) & 0xFFFu);
+                    s = (int)(k.state >> 24);
+                    left = (int)k.count;
+                    out = pool + k.dst;
+                    win.valid = false;
+                    active = left > 0;
+                } else {
+                    exhausted = true;
+                }
+            }
+        }
+        if (!__any(active)) break;
+        if (__any(active && !win.covers(cx, cy))) {
+            if (active && win.near_edge(cx, cy)) win.recentre(plane, WS, H, cx, cy, tile, lane);
+        }
+        if (active) {
+            const uint32_t m = win.mask(tile, lane, cx, cy);
+            if (s >= 8) {  // fresh start: initial search (s - 8 = hole flag)
+                const int s0 = fresh_dir(m, s == 9);
+                s = s0 < 0 ? 0 : s0;  // a single pixel has count 1 and stops below before s is used
+            }
+            *out++ = (uint32_t)cx | ((uint32_t)cy << 16);
+            if (--left == 0) {
                 active = false;
-                if (!STORE && res >= cfg.minPerim && res <= cfg.maxPerim) emit_contour(c, res, contours, contourCap, poolCap, ctr);
+            } else {
+                const uint32_t rot = ((m >> (s + 1)) | (m << (7 - s))) & 0xFFu;
+                const int d = (s + __ffs(rot)) & 7;
+                cx += fast_dx(d);
+                cy += fast_dy(d);
+                s = d ^ 4;
             }
         }
     }
@@ -592,12 +748,11 @@ void launch_contour_starts(const DetCfg& c, const DetBuffers& b, int B, hipStrea
 
 void launch_trace(const DetCfg& c, const DetBuffers& b, hipStream_t st) {
     hipLaunchKernelGGL(k_trace_short, dim3(256 * 8), dim3(256), 0, st, b.planes, c, b.cand, b.candCap, b.candLong,
-                       b.contours, b.contourCap, b.poolCap, b.counters);
+                       b.contours, b.contourCap, b.poolCap, b.tasks, b.taskCap, b.counters);
     // persistent: 10 single-wave workgroups per CU (16 KiB of LDS each)
-    hipLaunchKernelGGL(k_trace_tile<false>, dim3(256 * 10), dim3(64), 0, st, b.planes, c, b.candLong, b.candCap, b.contours,
-                       b.contourCap, b.pool, b.poolCap, b.counters);
-    hipLaunchKernelGGL(k_trace_tile<true>, dim3(256 * 10), dim3(64), 0, st, b.planes, c, b.candLong, b.candCap, b.contours,
-                       b.contourCap, b.pool, b.poolCap, b.counters);
+    hipLaunchKernelGGL(k_trace_decide, dim3(kTraceWaves), dim3(64), 0, st, b.planes, c, b.candLong, b.candCap, b.contours,
+                       b.contourCap, b.poolCap, b.tasks, b.taskCap, b.ckpt, b.counters);
+    hipLaunchKernelGGL(k_trace_store, dim3(kTraceWaves), dim3(64), 0, st, b.planes, c, b.tasks, b.taskCap, b.pool, b.counters);
 }
 
 }  // namespace camsync
