@@ -89,6 +89,7 @@ def load_library() -> C.CDLL:
         lib.camsync_debug_counts.argtypes = [vp, i32, vp]
         lib.camsync_debug_quads.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp]
         lib.camsync_debug_contours.argtypes = [vp, i32, i32, vp, vp, vp, vp]
+        lib.camsync_debug_points.argtypes = [vp, i32, i32, vp]
         lib.camsync_pnp_batch.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, vp, vp, vp]
         lib.camsync_ippe_square_batch.argtypes = [vp, vp, vp, i32, vp, vp, i32, i32, vp, vp, vp]
         lib.camsync_detect_pnp_batch.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp, i32, i32,
@@ -240,6 +241,13 @@ class Context:
             self._check(n)
         n = min(n, cap)
         return dict(scale=sc[:n], start_key=key[:n], is_hole=hole[:n], length=ln[:n])
+
+    def debug_points(self, frame=0, cap=1 << 20):
+        xy = np.zeros((cap, 2), np.int32)
+        n = self._lib.camsync_debug_points(self._h, frame, cap, _ptr(xy))
+        if n < 0:
+            self._check(n)
+        return xy[:min(n, cap)]
 
     # -- pose ----------------------------------------------------------
     def pnp(self, obj, img, npts, K, dist):

@@ -340,11 +340,12 @@ int camsync_create(camsync_ctx** out, int device, int max_h, int max_w, int max_
     b.candCap = (unsigned)std::min<size_t>(std::max<size_t>(B * (px / 32), 1u << 16), 0x7FFFFFFFu);
     HIPCHK(c, dalloc(&b.cand, b.candCap));
     HIPCHK(c, dalloc(&b.candLong, b.candCap));
-    b.contourCap = (unsigned)std::min<size_t>(B * 4096, 0x7FFFFFFFu);
+    // (+ the blocks the persistent border-follower waves reserve and may leave partly unused)
+    b.contourCap = (unsigned)std::min<size_t>(B * 4096 + (size_t)kTraceWaves * 32, 0x7FFFFFFFu);
     HIPCHK(c, dalloc(&b.contours, b.contourCap));
-    b.poolCap = (unsigned)std::min<size_t>(B * (size_t)262144, 0x7FFFFFFFu);
+    b.poolCap = (unsigned)std::min<size_t>(B * (size_t)262144 + (size_t)kTraceWaves * 16384, 0x7FFFFFFFu);
     HIPCHK(c, dalloc(&b.pool, b.poolCap));
-    b.taskCap = (unsigned)std::min<size_t>((size_t)b.contourCap * 2 + b.poolCap / kCkStride + 64, 0x7FFFFFFFu);
+    b.taskCap = (unsigned)std::min<size_t>((size_t)b.contourCap * 2 + b.poolCap / kCkStride + (size_t)kTraceWaves * 128, 0x7FFFFFFFu);
     HIPCHK(c, dalloc(&b.tasks, b.taskCap));
     HIPCHK(c, dalloc(&b.ckpt, (size_t)kTraceWaves * 32 * 2 * kCkMax));
     HIPCHK(c, dalloc(&b.quads, B * kQuadCap));
@@ -676,6 +677,29 @@ int camsync_debug_contours(camsync_ctx* c, int frame, int max_contours, int32_t*
             if (length) length[k] = (int32_t)h[i].len;
         }
         k++;
+    }
+    return k;
+}
+
+int camsync_debug_points(camsync_ctx* c, int frame, int max_points, int32_t* xy) {
+    if (!c || frame < 0 || frame >= c->lastB || !xy) return CAMSYNC_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    Counters hc;
+    HIPCHK(c, hipMemcpy(&hc, c->buf.counters, sizeof hc, hipMemcpyDeviceToHost));
+    const unsigned n = std::min(hc.nContours, c->buf.contourCap);
+    std::vector<ContourRec> h(n);
+    if (n) HIPCHK(c, hipMemcpy(h.data(), c->buf.contours, sizeof(ContourRec) * n, hipMemcpyDeviceToHost));
+    int k = 0;
+    std::vector<uint32_t> pts;
+    for (unsigned i = 0; i < n; i++) {
+        if ((int)h[i].frame != frame) continue;
+        pts.resize(h[i].len);
+        if (h[i].len) HIPCHK(c, hipMemcpy(pts.data(), c->buf.pool + h[i].off, sizeof(uint32_t) * h[i].len, hipMemcpyDeviceToHost));
+        for (uint32_t j = 0; j < h[i].len; j++, k++)
+            if (k < max_points) {
+                xy[2 * k] = (int32_t)(pts[j] & 0xFFFFu);
+                xy[2 * k + 1] = (int32_t)(pts[j] >> 16);
+            }
     }
     return k;
 }

@@ -514,6 +514,81 @@ __device__ __forceinline__ uint32_t from_partner(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
 }
 
+// A wave takes work from a global queue in batches and hands the items to its idle lanes, and it reserves
+// output space (points, contour records, store tasks) in blocks that it sub-allocates itself: the global
+// counters are touched once per block instead of once per border (they are single hot addresses).
+constexpr unsigned int kPoolBlock = 16384, kSlotBlock = 8, kTaskBlock = 128, kDecideBatch = 64, kStoreBatch = 256;
+
+struct WaveQueue {
+    unsigned int lo = 0, hi = 0;
+    bool drained = false;
+    // every lane calls this; returns the item index for lanes with want == true (rank order) or ~0u if none is left
+    // for them right now.  `unit` lanes form one consumer (pairs: unit = 2, the even lane's want counts).
+    template <int UNIT>
+    __device__ __forceinline__ unsigned int pop(bool want, unsigned int* head, unsigned int n, unsigned int batch, int lane) {
+        unsigned long long bal = __ballot(want);
+        if (UNIT == 2) bal &= 0x5555555555555555ull;
+        if (!bal) return ~0u;
+        if (lo == hi && !drained) {
+            unsigned int b = 0;
+            if (lane == 0) b = atomicAdd(head, batch);
+            b = __builtin_amdgcn_readfirstlane(b);
+            lo = b < n ? b : n;
+            hi = b + batch < n ? b + batch : n;
+            if (b + batch >= n) drained = true;
+        }
+        const unsigned int rank = (unsigned int)__popcll(bal & ((1ull << (lane & ~(UNIT - 1))) - 1ull));
+        const unsigned int avail = hi - lo, cnt = (unsigned int)__popcll(bal);
+        const unsigned int idx = (want && rank < avail) ? lo + rank : ~0u;
+        lo += cnt < avail ? cnt : avail;
+        return idx;
+    }
+    __device__ __forceinline__ bool empty() const { return drained && lo == hi; }
+};
+
+struct WaveAlloc {
+    unsigned int cur = 0, end = 0;
+    // uniform call: reserve `need` consecutive entries; refills from the global counter by blocks.
+    // Returns ~0u (and raises the overflow bit) when the list is full.  `left` receives the abandoned tail
+    // [left.x, left.y) of the previous block when a refill happens (the caller marks those entries empty).
+    __device__ __forceinline__ unsigned int take(unsigned int need, unsigned int block, unsigned int* counter, unsigned int cap,
+                                                 unsigned int ovfBit, Counters* ctr, int lane, uint2& left) {
+        left = make_uint2(0, 0);
+        if (cur + need > end) {
+            left = make_uint2(cur, end);
+            const unsigned int sz = need > block ? need : block;
+            unsigned int b = 0;
+            if (lane == 0) b = atomicAdd(counter, sz);
+            b = __builtin_amdgcn_readfirstlane(b);
+            if (b + sz > cap) {
+                if (lane == 0) atomicOr(&ctr->overflow, ovfBit);
+                cur = end = 0;
+                return ~0u;
+            }
+            cur = b;
+            end = b + sz;
+        }
+        const unsigned int r = cur;
+        cur += need;
+        return r;
+    }
+};
+
+__device__ __forceinline__ void mark_empty_contours(ContourRec* __restrict__ contours, unsigned int lo, unsigned int hi, int lane) {
+    for (unsigned int i = lo + lane; i < hi; i += 64) {
+        ContourRec r;
+        r.frame = 0xFFFFFFFFu; r.pos = 0; r.len = 0; r.off = 0; r.scale = 0; r.hole = 0; r.scanKey = 0;
+        contours[i] = r;
+    }
+}
+__device__ __forceinline__ void mark_empty_tasks(StoreTask* __restrict__ tasks, unsigned int lo, unsigned int hi, int lane) {
+    for (unsigned int i = lo + lane; i < hi; i += 64) {
+        StoreTask k;
+        k.plane = 0; k.state = 0; k.dst = 0; k.count = 0;
+        tasks[i] = k;
+    }
+}
+
 // Decide the long candidates (canonical start? length within bounds?), reserve pool space and cut the accepted
 // borders into store tasks.  Lanes 2p (forward) and 2p + 1 (backward) work on the same candidate.
 __global__ __launch_bounds__(64) void k_trace_decide(const uint32_t* __restrict__ planes, DetCfg cfg,
@@ -537,19 +612,16 @@ __global__ __launch_bounds__(64) void k_trace_decide(const uint32_t* __restrict_
     TileWin win;
     win.gx = win.gy = 0;
     win.valid = false;
+    WaveQueue queue;
+    WaveAlloc poolA, slotA, taskA;
 
     for (;;) {
         // ---- idle pairs fetch their next candidate (the queue hands out every index below n exactly once) ----
-        const bool need = !active && !exhausted;
-        const unsigned long long bal = __ballot(need) & 0x5555555555555555ull;  // one bit per pair
-        if (bal) {
-            const int leader = __ffsll((long long)bal) - 1;
-            unsigned int qb = 0;
-            if (lane == leader) qb = atomicAdd(&ctr->qDecide, (unsigned int)__popcll(bal));
-            qb = __shfl(qb, leader, 64);
+        {
+            const bool need = !active && !exhausted;
+            const unsigned int i = queue.pop<2>(need, &ctr->qDecide, n, kDecideBatch, lane);
             if (need) {
-                const unsigned int i = qb + (unsigned int)__popcll(bal & ((1ull << (lane & ~1)) - 1ull));
-                if (i < n) {
+                if (i != ~0u) {
                     c = candLong[i];
                     const uint32_t pos = (uint32_t)(c & 0xFFFFFFFFull);
                     plane = planes + ((size_t)(uint32_t)(c >> 40) * S + (int)((c >> 36) & 7u)) * perPlane;
@@ -561,12 +633,15 @@ __global__ __launch_bounds__(64) void k_trace_decide(const uint32_t* __restrict_
                     win.valid = false;
                     active = true;
                     fresh = true;
-                } else {
+                } else if (queue.empty()) {
                     exhausted = true;
                 }
             }
         }
-        if (!__any(active)) break;
+        if (!__any(active)) {
+            if (__all(exhausted)) break;
+            continue;  // e.g. every lane drew an empty task: draw again
+        }
 
         // ---- keep every active lane's window around its pixel ----
         if (__any(active && !win.covers(cx, cy))) {
@@ -635,39 +710,66 @@ __global__ __launch_bounds__(64) void k_trace_decide(const uint32_t* __restrict_
             if (total > cfg.maxPerim) res = 0;
         }
         if (active) prevState = bw ? newState : newState;
+        // ---- accepted borders: the wave hands out space border by border (uniform loop), then the pair writes ----
+        const bool accept = res >= cfg.minPerim && res <= cfg.maxPerim;
+        const unsigned int nt = (unsigned int)((count + kCkStride - 1) / kCkStride);  // tasks of this lane's half
+        unsigned int myOff = ~0u, mySlot = ~0u, myTask = ~0u;
+        unsigned long long am = __ballot(accept && !bw);
+        while (am) {
+            const int l = __ffsll((long long)am) - 1;
+            am &= am - 1;
+            const unsigned int len = (unsigned int)__shfl(res, l, 64), ntl = __shfl(nt, l, 64);
+            uint2 left;
+            const unsigned int off = poolA.take(len, kPoolBlock, &ctr->nPool, poolCap, 4u, ctr, lane, left);
+            const unsigned int slot = slotA.take(1, kSlotBlock, &ctr->nContours, contourCap, 2u, ctr, lane, left);
+            const unsigned int t0 = taskA.take(2 * ntl, kTaskBlock, &ctr->nTasks, taskCap, 64u, ctr, lane, left);
+            mark_empty_tasks(tasks, left.x, left.y, lane);
+            if ((lane & ~1) == l && off != ~0u && slot != ~0u && t0 != ~0u) {
+                myOff = off;
+                mySlot = slot;
+                myTask = t0 + (bw ? ntl : 0u);
+            }
+        }
         if (res >= 0) {
             active = false;
-            if (res >= cfg.minPerim && res <= cfg.maxPerim) {
-                // forward lane reserves the space, both lanes cut their half into tasks
-                unsigned int off = ~0u;
-                if (!bw) off = emit_contour(c, res, contours, contourCap, poolCap, ctr);
-                off = __shfl(off, lane & ~1, 64);
-                const unsigned int nt = (unsigned int)((count + kCkStride - 1) / kCkStride);
-                const unsigned int t0 = off != ~0u ? reserve_tasks(nt, taskCap, ctr) : ~0u;
-                if (t0 != ~0u) {
-                    const uint32_t planeIdx = (uint32_t)(c >> 40) * S + (uint32_t)((c >> 36) & 7u);
-                    for (unsigned int t = 0; t < nt; t++) {
-                        StoreTask k;
-                        k.plane = planeIdx;
-                        if (!bw) {
-                            // points [t*stride, min((t+1)*stride, count)) from the start or a checkpoint
-                            k.state = t == 0 ? state0 : myCk[t];
-                            k.dst = off + t * kCkStride;
-                            k.count = min((unsigned int)kCkStride, (unsigned int)count - t * kCkStride);
-                        } else {
-                            // the backward lane's states B_1..B_count are points res-1 ... res-count; piece t
-                            // starts at B_e, e = min((t+1)*stride, count), and runs forward for e - t*stride points
-                            const unsigned int e = min((t + 1) * (unsigned int)kCkStride, (unsigned int)count);
-                            k.state = e == (unsigned int)count ? prevState : myCk[t + 1];
-                            k.dst = off + (unsigned int)res - e;
-                            k.count = e - t * kCkStride;
-                        }
-                        tasks[t0 + t] = k;
+            if (accept && myOff != ~0u) {
+                const uint32_t planeIdx = (uint32_t)(c >> 40) * S + (uint32_t)((c >> 36) & 7u);
+                if (!bw) {
+                    const uint32_t pos = (uint32_t)(c & 0xFFFFFFFFull);
+                    ContourRec r;
+                    r.frame = (uint32_t)(c >> 40);
+                    r.pos = pos;
+                    r.len = (uint32_t)res;
+                    r.off = myOff;
+                    r.scale = (uint16_t)((c >> 36) & 7u);
+                    r.hole = isHole ? 1 : 0;
+                    r.scanKey = pos + (isHole ? 1u : 0u);
+                    contours[mySlot] = r;
+                }
+                for (unsigned int t = 0; t < nt; t++) {
+                    StoreTask k;
+                    k.plane = planeIdx;
+                    if (!bw) {
+                        // points [t*stride, min((t+1)*stride, count)) from the start or a checkpoint
+                        k.state = t == 0 ? state0 : myCk[t];
+                        k.dst = myOff + t * kCkStride;
+                        k.count = min((unsigned int)kCkStride, (unsigned int)count - t * kCkStride);
+                    } else {
+                        // the backward lane's states B_1..B_count are points res-1 ... res-count; piece t
+                        // starts at B_e, e = min((t+1)*stride, count), and runs forward for e - t*stride points
+                        const unsigned int e = min((t + 1) * (unsigned int)kCkStride, (unsigned int)count);
+                        k.state = e == (unsigned int)count ? prevState : myCk[t + 1];
+                        k.dst = myOff + (unsigned int)res - e;
+                        k.count = e - t * kCkStride;
                     }
+                    tasks[myTask + t] = k;
                 }
             }
         }
     }
+    // entries reserved but never used must read as empty
+    mark_empty_contours(contours, slotA.cur, slotA.end, lane);
+    mark_empty_tasks(tasks, taskA.cur, taskA.end, lane);
 }
 
 // Write the points of the accepted borders: one lane per store task.
@@ -687,18 +789,14 @@ __global__ __launch_bounds__(64) void k_trace_store(const uint32_t* __restrict__
     TileWin win;
     win.gx = win.gy = 0;
     win.valid = false;
+    WaveQueue queue;
 
     for (;;) {
-        const bool need = !active && !exhausted;
-        const unsigned long long bal = __ballot(need);
-        if (bal) {
-            const int leader = __ffsll((long long)bal) - 1;
-            unsigned int qb = 0;
-            if (lane == leader) qb = atomicAdd(&ctr->qStore, (unsigned int)__popcll(bal));
-            qb = __shfl(qb, leader, 64);
+        {
+            const bool need = !active && !exhausted;
+            const unsigned int i = queue.pop<1>(need, &ctr->qStore, n, kStoreBatch, lane);
             if (need) {
-                const unsigned int i = qb + (unsigned int)__popcll(bal & ((1ull << lane) - 1ull));
-                if (i < n) {
+                if (i != ~0u) {
                     const StoreTask k = tasks[i];
                     plane = planes + (size_t)k.plane * perPlane;
                     cx = (int)(k.state & 0xFFFu);
@@ -708,12 +806,15 @@ __global__ __launch_bounds__(64) void k_trace_store(const uint32_t* __restrict__
                     out = pool + k.dst;
                     win.valid = false;
                     active = left > 0;
-                } else {
+                } else if (queue.empty()) {
                     exhausted = true;
                 }
             }
         }
-        if (!__any(active)) break;
+        if (!__any(active)) {
+            if (__all(exhausted)) break;
+            continue;  // e.g. every lane drew an empty task: draw again
+        }
         if (__any(active && !win.covers(cx, cy))) {
             if (active && win.near_edge(cx, cy)) win.recentre(plane, WS, H, cx, cy, tile, lane);
         }

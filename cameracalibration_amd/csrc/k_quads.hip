@@ -38,6 +38,7 @@ __global__ __launch_bounds__(64) void k_quad_fit(const ContourRec* __restrict__ 
         __syncthreads();
         const ContourRec rec = contours[ci];
         const int n = (int)rec.len;
+        if (n == 0) continue;  // a slot a border-follower wave reserved and did not use
         const uint32_t* __restrict__ P = pool + rec.off;
         double eps = (double)n * cfg.accuracyRate;
         eps *= eps;

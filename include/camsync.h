@@ -115,13 +115,15 @@ int camsync_detect_batch(camsync_ctx* ctx, const uint8_t* frames, int on_device,
  *                          key of the contour start, contour length, identified id (-1 = rejected), rotation
  *   camsync_debug_contours contours of `frame`: threshold scale, raster key of the start pixel, hole flag,
  *                          length in points
- * The quad/contour calls return the number of elements available (may exceed the capacity passed), or <0. */
+ *   camsync_debug_points   the points of those contours, concatenated in the same order: xy i32 [n,2]
+ * The quad/contour/point calls return the number of elements available (may exceed the capacity passed), or <0. */
 int camsync_debug_counts(camsync_ctx* ctx, int frame, int32_t out[8]);
 int camsync_debug_quads(camsync_ctx* ctx, int frame, int max_quads, float* corners,
                         int32_t* scale, int32_t* scan_key, int32_t* contour_len,
                         int32_t* id, int32_t* rot);
 int camsync_debug_contours(camsync_ctx* ctx, int frame, int max_contours, int32_t* scale,
                            int32_t* start_key, int32_t* is_hole, int32_t* length);
+int camsync_debug_points(camsync_ctx* ctx, int frame, int max_points, int32_t* xy);
 
 /* ---- pose ----------------------------------------------------------- */
 

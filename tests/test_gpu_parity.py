@@ -85,6 +85,32 @@ def test_contours_match_sequential_border_following(ctx, name):
     assert got == want, f"missing {len(want - got)} extra {len(got - want)}"
 
 
+@pytest.mark.parametrize("name", ["pic_1.png", "pic_2.png"])
+def test_contour_points_bit_exact(ctx, name):
+    """Every kept contour has exactly OpenCV's point list (order and start included), twice in a row
+    (the second call must not see anything left over from the first)."""
+    bgr = _data.load_bgr(name)
+    h, w = bgr.shape[:2]
+    minp, maxp = int(0.03 * max(h, w)), int(4.0 * max(h, w))
+    want = {}
+    for s, ob in enumerate(_oracle_bin(orc.bgr2gray(bgr))):
+        for c in orc.find_contours(ob):
+            if minp <= len(c) <= maxp:
+                want[(s, int(c[0][1]) * w + int(c[0][0]), len(c))] = c
+    for _ in range(2):
+        ctx.detect(bgr)
+        d = ctx.debug_contours(0, cap=65536)
+        pts = ctx.debug_points(0)
+        assert len(pts) == int(d["length"].sum())
+        off = 0
+        bad = []
+        for s, k, n in zip(d["scale"].tolist(), d["start_key"].tolist(), d["length"].tolist()):
+            if not np.array_equal(pts[off:off + n], want[(s, k, n)]):
+                bad.append((s, k, n, int(np.argmax((pts[off:off + n] != want[(s, k, n)]).any(axis=1)))))
+            off += n
+        assert not bad, bad[:10]
+
+
 def _reorder(q):
     q = q.copy()
     d1 = q[1] - q[0]
