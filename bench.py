@@ -85,7 +85,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--frames", type=int, default=4096, help="frames per GPU per step")
-    ap.add_argument("--chunk", type=int, default=256, help="frames per kernel launch sequence")
+    ap.add_argument("--chunk", type=int, default=4096, help="frames per kernel launch sequence")
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--cpu-sample", type=int, default=48)
