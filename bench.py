@@ -172,6 +172,17 @@ def main():
     alg_bytes = ALG_BYTES_PER_PX_K1K2 * B * H * W
     achieved = alg_bytes / (ms0 * 1e-3) / 1e9 if ms0 > 0 else 0.0
     stage_ms = {k: round(v[0], 3) for k, v in tm.items()}
+    # HBM traffic of that kernel from the PMC passes (FETCH_SIZE / WRITE_SIZE cannot be collected from inside this
+    # process): profiles/*_pmc_k_gray_thresh3.json holds the corrected bytes per pixel measured with rocprofv3 on this
+    # same command; it is scaled to this run's launch size only when the frame geometry matches.
+    traffic = None
+    try:
+        import glob
+        pm = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_k_gray_thresh3.json")))[-1]))
+        if (pm["config"]["height"], pm["config"]["width"]) == (H, W) and pm["config"]["frames_per_launch"] == min(args.chunk, B):
+            traffic = pm["traffic_bytes_per_px"] * px_per_launch
+    except Exception:
+        traffic = None
 
     out = None
     if rank == 0:
@@ -193,7 +204,9 @@ def main():
                                    f"6 markers (v1 sheet), 4 anchors, chunk {min(args.chunk, B)}",
                        "frames_per_gpu": B, "height": H, "width": W, "parallelism": f"frames sharded x{world}"},
             "roofline": {"bound": "hbm", "kernel": "k_gray_thresh3 (K1+K2 fused)", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes, profiles/)",
+                         "algorithmic_bytes_per_launch": ALG_BYTES_PER_PX_K1K2 * px_per_launch,
                          "algorithmic_bytes_per_px": ALG_BYTES_PER_PX_K1K2, "px_per_launch": px_per_launch,
                          "avg_launch_ms": ms0 / max(n0, 1),
                          "pipeline_frac_k1k3": (ALG_BYTES_PER_PX_K1K3 * H * W * value / max(world, 1)) / 1e9 / HBM_PEAK_GBS},
