@@ -29,6 +29,15 @@ constexpr int ROWPX = PX * TPB;  // 512
 constexpr int HALO = 16;         // >= max radius, multiple of PX
 constexpr int CHUNKW = ROWPX - 2 * HALO;
 
+// The workgroup is one wavefront and a wavefront's LDS operations execute in order, so exchanging data
+// between lanes through LDS needs no s_barrier and, above all, no wait for the global loads in flight
+// (which __syncthreads() would add, serialising the row prefetch): only the compiler must keep the order.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ uint32_t luma(uint32_t b, uint32_t g, uint32_t r) {
     return (b * 3735u + g * 19235u + r * 9798u + 16384u) >> 15;
 }
@@ -102,19 +111,22 @@ __device__ __forceinline__ void widen8(uint2 v, uint32_t o[4]) {
 }
 
 // Sliding horizontal sum of radius R over the exchanged vertical sums.
-// xb points at this scale's row of u16 sums; base = PX*lane.
+// xb points at this scale's row of u16 sums; base = PX*lane.  The values come in with 16-byte reads on a
+// 16-byte lane stride (conflict-free); 4-byte reads on that stride would hit every bank four times.
 template <int R>
 __device__ __forceinline__ void hsum8(const uint16_t* xb, int base, uint32_t out[8]) {
-    // window of pixel i covers [base+i-R, base+i+R]; gather [lo, lo+N) with lo even
-    constexpr int LO = (R + 1) & ~1;             // even offset >= R
-    constexpr int N = 8 + 2 * LO;                // values fetched
+    // window of pixel i covers [base+i-R, base+i+R]; gather [base-LO, base+8+LO) with LO a multiple of 8
+    constexpr int LO = ((R + 7) / 8) * 8;
+    constexpr int N = 8 + 2 * LO;  // values fetched
     uint32_t v[N];
-    const uint32_t* p = reinterpret_cast<const uint32_t*>(xb + base - LO);
+    const uint4* p = reinterpret_cast<const uint4*>(xb + base - LO);
 #pragma unroll
-    for (int i = 0; i < N / 2; i++) {
-        uint32_t w = p[i];
-        v[2 * i] = w & 0xFFFFu;
-        v[2 * i + 1] = w >> 16;
+    for (int i = 0; i < N / 8; i++) {
+        const uint4 w = p[i];
+        v[8 * i + 0] = w.x & 0xFFFFu; v[8 * i + 1] = w.x >> 16;
+        v[8 * i + 2] = w.y & 0xFFFFu; v[8 * i + 3] = w.y >> 16;
+        v[8 * i + 4] = w.z & 0xFFFFu; v[8 * i + 5] = w.z >> 16;
+        v[8 * i + 6] = w.w & 0xFFFFu; v[8 * i + 7] = w.w >> 16;
     }
     uint32_t s = 0;
 #pragma unroll
@@ -174,7 +186,7 @@ __global__ __launch_bounds__(TPB) void k_gray_thresh3(const uint8_t* __restrict_
     const int bx0 = cx0 >> 5;  // first plane block of this strip (CHUNKW is a multiple of 32)
     // write rows [16 hb, 16 hb + 16) of the strip's blocks to the three planes
     auto flush = [&](int hb) {
-        __syncthreads();
+        wave_lds_sync();
         for (int i = tid; i < 3 * NBLK * 4; i += TPB) {
             const int sc = i / (NBLK * 4), rem = i - sc * (NBLK * 4), blk = rem >> 2, q = rem & 3;
             if (bx0 + blk < WS) {
@@ -183,7 +195,7 @@ __global__ __launch_bounds__(TPB) void k_gray_thresh3(const uint8_t* __restrict_
                 *reinterpret_cast<uint4*>(dst) = v;
             }
         }
-        __syncthreads();
+        wave_lds_sync();
     };
     uint8_t* const myStage = reinterpret_cast<uint8_t*>(&stage[0][0][0]) + (((tid - HALO / PX) >> 2) * 16) * 4 + ((tid - HALO / PX) & 3);
 
@@ -232,11 +244,11 @@ __global__ __launch_bounds__(TPB) void k_gray_thresh3(const uint8_t* __restrict_
         for (int i = 0; i < 4; i++) V0[i] = V0[i] + a[i] - b[i];
 
         // exchange vertical sums (single wavefront: the barrier only orders this wave's LDS traffic)
-        __syncthreads();
+        wave_lds_sync();
         *reinterpret_cast<uint4*>(&xbuf[0][HALO + PX * tid]) = make_uint4(V0[0], V0[1], V0[2], V0[3]);
         *reinterpret_cast<uint4*>(&xbuf[1][HALO + PX * tid]) = make_uint4(V1[0], V1[1], V1[2], V1[3]);
         *reinterpret_cast<uint4*>(&xbuf[2][HALO + PX * tid]) = make_uint4(V2[0], V2[1], V2[2], V2[3]);
-        __syncthreads();
+        wave_lds_sync();
 
         if (inOut) {
             const uint2 cen = *reinterpret_cast<const uint2*>(&ring[slot(y)][PX * tid]);
