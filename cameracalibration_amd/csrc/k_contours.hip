@@ -50,7 +50,7 @@ __device__ __forceinline__ uint32_t fill_down(uint32_t seed, uint32_t run) {
     return f;
 }
 
-constexpr int kStage = 2048;  // starts staged per workgroup before a flush
+constexpr int kStage = 512;  // starts staged per wavefront before a flush
 
 // word (xw, y) of a block-linear plane, zero outside the plane
 __device__ __forceinline__ uint32_t pw(const uint32_t* __restrict__ plane, int WS, int H, int xw, int y) {
@@ -58,165 +58,189 @@ __device__ __forceinline__ uint32_t pw(const uint32_t* __restrict__ plane, int W
     return plane[plane_word_index(WS, xw, y)];
 }
 
-// One thread per word, in memory order (a wave reads two whole cache lines of the centre row set).
+// A wavefront handles two horizontally adjacent plane blocks per round: lane = (block, row), so the centre
+// words are two whole cache lines, the rows above come from the neighbouring lanes, and nothing is divided
+// per thread.  Waves own contiguous ranges of block pairs and stage their starts in a private LDS list
+// (no workgroup barriers); the global list is appended to with one atomic per flush.
 __global__ __launch_bounds__(256) void k_contour_starts(const uint32_t* __restrict__ planes, DetCfg cfg, int B,
                                                         uint64_t* __restrict__ cand, unsigned int candCap,
                                                         Counters* __restrict__ ctr) {
-    __shared__ unsigned int s_cnt, s_base;
-    __shared__ uint64_t s_list[kStage];
-    const int H = cfg.H, WS = cfg.WS, S = cfg.nScales, W = cfg.W;
+    __shared__ uint64_t s_list[4][kStage];
+    const int H = cfg.H, WS = cfg.WS, S = cfg.nScales, W = cfg.W, HB = plane_hb(H);
+    const int WP = (WS + 1) >> 1;
     const size_t perPlane = plane_words(H, WS);
-    const size_t total = (size_t)B * S * perPlane;
     const bool dropIsolated = cfg.minPerim > 1;
-    if (threadIdx.x == 0) s_cnt = 0;
-    __syncthreads();
-    for (size_t base = (size_t)blockIdx.x * blockDim.x; base < total; base += (size_t)gridDim.x * blockDim.x) {
-        const size_t i = base + threadIdx.x;
-        uint32_t outer = 0, hole = 0;
-        int f = 0, sc = 0, y = 0, xw = 0;
-        if (i < total) {
-            const size_t fs = i / perPlane;
-            const size_t wi = i - fs * perPlane;
-            const int blk = (int)(wi >> 5);
-            xw = blk % WS;
-            y = (blk / WS) * 32 + (int)(wi & 31);
-            sc = (int)(fs % S);
-            f = (int)(fs / S);
-            if (y >= 1 && y <= H - 2) {
-                const uint32_t* plane = planes + fs * perPlane;
-                const uint32_t c = plane[wi];
-                const uint32_t n = pw(plane, WS, H, xw, y - 1);
-                if (c | n) {  // nothing can start in an all-zero word under an all-zero word
-                    const uint32_t cl = pw(plane, WS, H, xw - 1, y), cr = pw(plane, WS, H, xw + 1, y);
-                    const uint32_t nl = pw(plane, WS, H, xw - 1, y - 1), nr = pw(plane, WS, H, xw + 1, y - 1);
-                    const uint32_t w = (c << 1) | (cl >> 31);
-                    const uint32_t nw = (n << 1) | (nl >> 31);
-                    const uint32_t ne = (n >> 1) | (nr << 31);
-                    const uint32_t above = n | nw | ne;  // some foreground 8-adjacent in the row above
-                    outer = c & ~w & ~above;
-                    hole = ~c & w & n;
-                    if ((xw + 1) * 32 > W) {  // pixels beyond the image width are padding, never starts
-                        const uint32_t valid = (1u << (W - xw * 32)) - 1u;
-                        hole &= valid;
-                    }
-                    if (outer) {
-                        // the run that starts here must not touch the row above anywhere
-                        outer &= ~fill_down(above, c);
-                        // a run that leaves the word through bit 31 is followed into the next words
-                        if ((c >> 31) && outer) {
-                            const uint32_t top = 1u << (32 - __clz(~c));  // lowest bit of the run ending at bit 31
-                            if (outer & top) {
-                                bool bad = false;
-                                for (int k = xw + 1; k < WS; k++) {
-                                    const uint32_t ck = pw(plane, WS, H, k, y);
-                                    if (!(ck & 1u)) break;
-                                    const uint32_t nk = pw(plane, WS, H, k, y - 1);
-                                    const uint32_t nkl = pw(plane, WS, H, k - 1, y - 1), nkr = pw(plane, WS, H, k + 1, y - 1);
-                                    const uint32_t ab = nk | (nk << 1) | (nkl >> 31) | (nk >> 1) | (nkr << 31);
-                                    const int t = __ffs(~ck) - 1;  // run covers bits [0,t), t = -1 means all 32
-                                    const uint32_t rmask = (t < 0) ? 0xFFFFFFFFu : ((1u << t) - 1u);
-                                    if (ab & rmask) { bad = true; break; }
-                                    if (t >= 0) break;
-                                }
-                                if (bad) outer &= ~top;
-                            }
-                        }
-                        if (dropIsolated && outer) {
-                            const uint32_t s = pw(plane, WS, H, xw, y + 1);
-                            const uint32_t sl = pw(plane, WS, H, xw - 1, y + 1), sr = pw(plane, WS, H, xw + 1, y + 1);
-                            const uint32_t e = (c >> 1) | (cr << 31);
-                            const uint32_t sw = (s << 1) | (sl >> 31);
-                            const uint32_t se = (s >> 1) | (sr << 31);
-                            outer &= (e | sw | s | se);
-                        }
-                    }
-                    if (hole) {
-                        // the zero run that starts here must have foreground directly above all along
-                        hole &= ~fill_down(~n, ~c);
-                        if (!(c >> 31) && hole) {
-                            const uint32_t top = 1u << (32 - __clz(c));  // lowest bit of the zero run ending at bit 31
-                            if (hole & top) {
-                                bool bad = false;
-                                for (int k = xw + 1; k < WS; k++) {
-                                    const uint32_t zk = ~pw(plane, WS, H, k, y);
-                                    if (!(zk & 1u)) break;
-                                    const uint32_t nz = ~pw(plane, WS, H, k, y - 1);
-                                    const int t = __ffs(~zk) - 1;
-                                    const uint32_t rmask = (t < 0) ? 0xFFFFFFFFu : ((1u << t) - 1u);
-                                    if (nz & rmask) { bad = true; break; }
-                                    if (t >= 0) break;
-                                }
-                                if (bad) hole &= ~top;
-                            }
-                        }
-                    }
-                }
-            }
-        }
-        // stage in LDS; flush when the staging area could overflow in the next round
-        const int cnt = __popc(outer) + __popc(hole);
-        unsigned int o = 0;
-        if (cnt) o = atomicAdd(&s_cnt, (unsigned int)cnt);
-        const bool fits = o + (unsigned int)cnt <= (unsigned int)kStage;
-        const uint32_t rowPos = (uint32_t)y * W + 32u * xw;
-        if (cnt && fits) {
-            uint32_t m = outer;
-            while (m) {
-                const int bit = __ffs(m) - 1;
-                m &= m - 1;
-                s_list[o++] = pack_cand(f, 0, sc, rowPos + bit);
-            }
-            m = hole;
-            while (m) {
-                const int bit = __ffs(m) - 1;
-                m &= m - 1;
-                s_list[o++] = pack_cand(f, 1, sc, rowPos + bit - 1);  // start pixel is left of the first hole pixel
-            }
-        }
-        __syncthreads();
-        const unsigned int staged = s_cnt;
-        const bool last = base + (size_t)gridDim.x * blockDim.x >= total;
-        if (staged > (unsigned int)kStage) {
-            // this round did not fit entirely: the threads left out append on their own, and the staging
-            // slots they had reserved (below kStage) are marked empty (~0) so the readers skip them
-            if (cnt && !fits) {
-                unsigned int g = atomicAdd(&ctr->nCand, (unsigned int)cnt);
-                if (g + cnt > candCap) {
-                    atomicOr(&ctr->overflow, 1u);
-                } else {
-                    uint32_t m = outer;
-                    while (m) {
-                        const int bit = __ffs(m) - 1;
-                        m &= m - 1;
-                        cand[g++] = pack_cand(f, 0, sc, rowPos + bit);
-                    }
-                    m = hole;
-                    while (m) {
-                        const int bit = __ffs(m) - 1;
-                        m &= m - 1;
-                        cand[g++] = pack_cand(f, 1, sc, rowPos + bit - 1);
-                    }
-                }
-                for (unsigned int k = o; k < o + (unsigned int)cnt && k < (unsigned int)kStage; k++) s_list[k] = ~0ull;
-            }
-            __syncthreads();
-        }
-        const unsigned int nflush = staged < (unsigned int)kStage ? staged : (unsigned int)kStage;
-        // a later round adds at most 256*32 starts; flush early enough that the common case never overflows
-        if (nflush && (last || staged > (unsigned int)(kStage - 512))) {
-            if (threadIdx.x == 0) s_base = atomicAdd(&ctr->nCand, nflush);
-            __syncthreads();
-            const unsigned int gb = s_base;
-            if (gb + nflush > candCap) {
-                if (threadIdx.x == 0) atomicOr(&ctr->overflow, 1u);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint64_t* const stage = s_list[wv];
+    unsigned int staged = 0;  // uniform
+
+    auto flush = [&]() {
+        if (staged) {
+            unsigned int g = 0;
+            if (lane == 0) g = atomicAdd(&ctr->nCand, staged);
+            g = __builtin_amdgcn_readfirstlane(g);
+            if (g + staged > candCap) {
+                if (lane == 0) atomicOr(&ctr->overflow, 1u);
             } else {
-                for (unsigned int k = threadIdx.x; k < nflush; k += blockDim.x) cand[gb + k] = s_list[k];
+                for (unsigned int k = lane; k < staged; k += 64) cand[g + k] = stage[k];
             }
-            __syncthreads();
-            if (threadIdx.x == 0) s_cnt = 0;
-            __syncthreads();
+            staged = 0;
+        }
+    };
+
+    const unsigned long long units = (unsigned long long)B * S * HB * WP;
+    const unsigned long long nw = (unsigned long long)gridDim.x * 4, w = (unsigned long long)blockIdx.x * 4 + wv;
+    unsigned long long u = units * w / nw;
+    const unsigned long long uEnd = units * (w + 1) / nw;
+    // decode once, then count up
+    int p = (int)(u % WP);
+    unsigned long long t = u / WP;
+    int by = (int)(t % HB);
+    unsigned int fs = (unsigned int)(t / HB);
+    // the words of a round are loaded one round ahead, so a wave always has a round's loads in flight
+    struct Words { uint32_t c, cl, cr, n, nl, nr; };
+    const int r = lane & 31;
+    auto load_unit = [&](int pp, int bby, unsigned int ffs) {
+        Words q = {0u, 0u, 0u, 0u, 0u, 0u};
+        const int bx = 2 * pp + (lane >> 5);
+        const uint32_t* plane = planes + (size_t)ffs * perPlane;
+        if (bx < WS) {
+            const size_t ci = ((size_t)bby * WS + bx) * 32 + r;
+            q.c = plane[ci];
+            if (bx > 0) q.cl = plane[ci - 32];
+            if (bx + 1 < WS) q.cr = plane[ci + 32];
+            if (r == 0 && bby > 0) {  // the row above the first row of a block lives in the block above
+                const size_t ai = ((size_t)(bby - 1) * WS + bx) * 32 + 31;
+                q.n = plane[ai];
+                if (bx > 0) q.nl = plane[ai - 32];
+                if (bx + 1 < WS) q.nr = plane[ai + 32];
+            }
+        }
+        return q;
+    };
+    Words cur = {0u, 0u, 0u, 0u, 0u, 0u};
+    if (u < uEnd) cur = load_unit(p, by, fs);
+    for (; u < uEnd; u++) {
+        int np = p + 1, nby = by;
+        unsigned int nfs = fs;
+        if (np == WP) {
+            np = 0;
+            if (++nby == HB) {
+                nby = 0;
+                nfs++;
+            }
+        }
+        Words nxt = {0u, 0u, 0u, 0u, 0u, 0u};
+        if (u + 1 < uEnd) nxt = load_unit(np, nby, nfs);
+
+        const int bx = 2 * p + (lane >> 5), y = by * 32 + r;
+        const uint32_t* plane = planes + (size_t)fs * perPlane;
+        const uint32_t c = cur.c, cl = cur.cl, cr = cur.cr;
+        // the row above: the lane before, except for the first row of a block
+        uint32_t n = __shfl_up(c, 1, 64), nl = __shfl_up(cl, 1, 64), nr = __shfl_up(cr, 1, 64);
+        if (r == 0) {
+            n = cur.n;
+            nl = cur.nl;
+            nr = cur.nr;
+        }
+        uint32_t outer = 0, hole = 0;
+        if ((c | n) && y <= H - 2) {  // nothing can start in an all-zero word under an all-zero word
+            const uint32_t wst = (c << 1) | (cl >> 31);
+            const uint32_t nw2 = (n << 1) | (nl >> 31);
+            const uint32_t ne = (n >> 1) | (nr << 31);
+            const uint32_t above = n | nw2 | ne;  // some foreground 8-adjacent in the row above
+            outer = c & ~wst & ~above;
+            hole = ~c & wst & n;
+            if ((bx + 1) * 32 > W) hole &= (1u << (W - bx * 32)) - 1u;  // pixels beyond the image width are padding
+            if (outer) {
+                // the run that starts here must not touch the row above anywhere
+                outer &= ~fill_down(above, c);
+                // a run that leaves the word through bit 31 is followed into the next words
+                if ((c >> 31) && outer) {
+                    const uint32_t top = 1u << (32 - __clz(~c));  // lowest bit of the run ending at bit 31
+                    if (outer & top) {
+                        bool bad = false;
+                        for (int k = bx + 1; k < WS; k++) {
+                            const uint32_t ck = pw(plane, WS, H, k, y);
+                            if (!(ck & 1u)) break;
+                            const uint32_t nk = pw(plane, WS, H, k, y - 1);
+                            const uint32_t nkl = pw(plane, WS, H, k - 1, y - 1), nkr = pw(plane, WS, H, k + 1, y - 1);
+                            const uint32_t ab = nk | (nk << 1) | (nkl >> 31) | (nk >> 1) | (nkr << 31);
+                            const int tt = __ffs(~ck) - 1;  // run covers bits [0,tt), tt = -1 means all 32
+                            const uint32_t rmask = (tt < 0) ? 0xFFFFFFFFu : ((1u << tt) - 1u);
+                            if (ab & rmask) { bad = true; break; }
+                            if (tt >= 0) break;
+                        }
+                        if (bad) outer &= ~top;
+                    }
+                }
+                if (dropIsolated && outer) {
+                    const uint32_t sd = pw(plane, WS, H, bx, y + 1);
+                    const uint32_t sl = pw(plane, WS, H, bx - 1, y + 1), sr = pw(plane, WS, H, bx + 1, y + 1);
+                    const uint32_t e = (c >> 1) | (cr << 31);
+                    const uint32_t sw = (sd << 1) | (sl >> 31);
+                    const uint32_t se = (sd >> 1) | (sr << 31);
+                    outer &= (e | sw | sd | se);
+                }
+            }
+            if (hole) {
+                // the zero run that starts here must have foreground directly above all along
+                hole &= ~fill_down(~n, ~c);
+                if (!(c >> 31) && hole) {
+                    const uint32_t top = 1u << (32 - __clz(c));  // lowest bit of the zero run ending at bit 31
+                    if (hole & top) {
+                        bool bad = false;
+                        for (int k = bx + 1; k < WS; k++) {
+                            const uint32_t zk = ~pw(plane, WS, H, k, y);
+                            if (!(zk & 1u)) break;
+                            const uint32_t nz = ~pw(plane, WS, H, k, y - 1);
+                            const int tt = __ffs(~zk) - 1;
+                            const uint32_t rmask = (tt < 0) ? 0xFFFFFFFFu : ((1u << tt) - 1u);
+                            if (nz & rmask) { bad = true; break; }
+                            if (tt >= 0) break;
+                        }
+                        if (bad) hole &= ~top;
+                    }
+                }
+            }
+        }
+        // ---- append this round's starts: one layer of the wave at a time (a word rarely holds more than one) ----
+        {
+            const uint32_t f = fs / (unsigned int)S, sc = fs % (unsigned int)S;
+            const uint32_t rowPos = (uint32_t)y * W + 32u * bx;
+            uint32_t mo = outer, mh = hole;
+            for (;;) {
+                const bool has = (mo | mh) != 0;
+                const unsigned long long bal = __ballot(has);
+                if (!bal) break;
+                const unsigned int layer = (unsigned int)__popcll(bal);
+                if (staged + layer > (unsigned int)kStage) flush();
+                if (has) {
+                    uint64_t v;
+                    if (mo) {
+                        v = pack_cand(f, 0, sc, rowPos + (__ffs(mo) - 1));
+                        mo &= mo - 1;
+                    } else {
+                        // the start pixel of a hole border is the pixel left of the hole's first pixel
+                        v = pack_cand(f, 1, sc, rowPos + (__ffs(mh) - 1) - 1);
+                        mh &= mh - 1;
+                    }
+                    stage[staged + (unsigned int)__popcll(bal & ((1ull << lane) - 1ull))] = v;
+                }
+                staged += layer;
+            }
+        }
+        cur = nxt;
+        // next block pair
+        if (++p == WP) {
+            p = 0;
+            if (++by == HB) {
+                by = 0;
+                fs++;
+            }
         }
     }
+    flush();
 }
 
 // 3-bit fields (x-1, x, x+1) of rows y-1, y, y+1 -> neighbour mask, bit d = neighbour in direction d.
@@ -841,9 +865,9 @@ __global__ __launch_bounds__(64) void k_trace_store(const uint32_t* __restrict__
 }  // namespace
 
 void launch_contour_starts(const DetCfg& c, const DetBuffers& b, int B, hipStream_t st) {
-    const size_t total = (size_t)B * c.nScales * plane_words(c.H, c.WS);
-    const size_t nblk = (total + 255) / 256;
-    const unsigned blocks = (unsigned)(nblk < (size_t)(256 * 16) ? nblk : (size_t)(256 * 16));
+    const unsigned long long units = (unsigned long long)B * c.nScales * plane_hb(c.H) * ((c.WS + 1) / 2);
+    const unsigned long long want = (units + 63) / 64;  // at least ~16 rounds per wave (4 waves per block)
+    const unsigned blocks = (unsigned)(want < 1 ? 1 : (want < (unsigned long long)(256 * 8) ? want : (unsigned long long)(256 * 8)));
     hipLaunchKernelGGL(k_contour_starts, dim3(blocks), dim3(256), 0, st, b.planes, c, B, b.cand, b.candCap, b.counters);
 }
 
