@@ -98,10 +98,10 @@ __global__ __launch_bounds__(256) void k_contour_starts(const uint32_t* __restri
     int by = (int)(t % HB);
     unsigned int fs = (unsigned int)(t / HB);
     // the words of a round are loaded one round ahead, so a wave always has a round's loads in flight
-    struct Words { uint32_t c, cl, cr, n, nl, nr; };
+    struct Words { uint32_t c, cl, cr, n, nl, nr, s, sl, sr; };
     const int r = lane & 31;
     auto load_unit = [&](int pp, int bby, unsigned int ffs) {
-        Words q = {0u, 0u, 0u, 0u, 0u, 0u};
+        Words q = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
         const int bx = 2 * pp + (lane >> 5);
         const uint32_t* plane = planes + (size_t)ffs * perPlane;
         if (bx < WS) {
@@ -115,10 +115,16 @@ __global__ __launch_bounds__(256) void k_contour_starts(const uint32_t* __restri
                 if (bx > 0) q.nl = plane[ai - 32];
                 if (bx + 1 < WS) q.nr = plane[ai + 32];
             }
+            if (r == 31 && bby + 1 < HB) {  // and the row below the last row in the block below
+                const size_t bi = ((size_t)(bby + 1) * WS + bx) * 32;
+                q.s = plane[bi];
+                if (bx > 0) q.sl = plane[bi - 32];
+                if (bx + 1 < WS) q.sr = plane[bi + 32];
+            }
         }
         return q;
     };
-    Words cur = {0u, 0u, 0u, 0u, 0u, 0u};
+    Words cur = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
     if (u < uEnd) cur = load_unit(p, by, fs);
     for (; u < uEnd; u++) {
         int np = p + 1, nby = by;
@@ -130,7 +136,7 @@ __global__ __launch_bounds__(256) void k_contour_starts(const uint32_t* __restri
                 nfs++;
             }
         }
-        Words nxt = {0u, 0u, 0u, 0u, 0u, 0u};
+        Words nxt = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
         if (u + 1 < uEnd) nxt = load_unit(np, nby, nfs);
 
         const int bx = 2 * p + (lane >> 5), y = by * 32 + r;
@@ -142,6 +148,13 @@ __global__ __launch_bounds__(256) void k_contour_starts(const uint32_t* __restri
             n = cur.n;
             nl = cur.nl;
             nr = cur.nr;
+        }
+        // the row below likewise (only the isolated-pixel test looks at it)
+        uint32_t sd = __shfl_down(c, 1, 64), sl = __shfl_down(cl, 1, 64), sr = __shfl_down(cr, 1, 64);
+        if (r == 31) {
+            sd = cur.s;
+            sl = cur.sl;
+            sr = cur.sr;
         }
         uint32_t outer = 0, hole = 0;
         if ((c | n) && y <= H - 2) {  // nothing can start in an all-zero word under an all-zero word
@@ -175,8 +188,6 @@ __global__ __launch_bounds__(256) void k_contour_starts(const uint32_t* __restri
                     }
                 }
                 if (dropIsolated && outer) {
-                    const uint32_t sd = pw(plane, WS, H, bx, y + 1);
-                    const uint32_t sl = pw(plane, WS, H, bx - 1, y + 1), sr = pw(plane, WS, H, bx + 1, y + 1);
                     const uint32_t e = (c >> 1) | (cr << 31);
                     const uint32_t sw = (sd << 1) | (sl >> 31);
                     const uint32_t se = (sd >> 1) | (sr << 31);
