@@ -7,8 +7,10 @@
 // halo, 480 produce output (1920 = 4 strips).  Each lane owns 8 adjacent
 // columns.  Per row the lane reads its 24 BGR bytes once (coalesced), converts
 // to luma with two byte dot products, writes the gray row, keeps the last
-// 2*rmax+2 gray rows in an LDS ring and maintains the vertical running sums of
-// the three windows in registers as packed 16-bit pairs.  The vertical sums
+// 2*rmax+2 gray rows (the newest rmax+1 in registers, the older rmax+1 in an LDS
+// ring: LDS per wave decides the occupancy, and this kernel lives on occupancy)
+// and maintains the vertical running sums of the three windows in registers as
+// packed 16-bit pairs.  The vertical sums
 // are exchanged through LDS and slid horizontally, so every input byte is
 // fetched from HBM once (plus the strip halos) and the three threshold images
 // leave as bit planes (one bit per pixel and scale).
@@ -156,13 +158,14 @@ template <int R0, int R1, int R2>
 __global__ __launch_bounds__(TPB) void k_gray_thresh3(const uint8_t* __restrict__ in, int C, uint8_t* __restrict__ gray,
                                                       uint8_t* __restrict__ bin, uint32_t* __restrict__ planes, int WS, int H, int W, int bandH, int idelta) {
     constexpr int RMAX = R2;
-    constexpr int RING = 2 * RMAX + 2;
+    constexpr int RING = RMAX + 1;  // rows y-1 .. y-rmax-1; rows y .. y+rmax sit in the register delay line
     static_assert(R0 <= R1 && R1 <= R2 && R2 <= HALO - 1, "radii must be sorted and fit the halo");
     __shared__ __align__(16) uint8_t ring[RING][ROWPX];
     __shared__ __align__(16) uint16_t xbuf[3][ROWPX + 2 * HALO];  // HALO columns of slack on both sides (edge lanes read there, unused)
     // 16 rows of plane bits of this strip, laid out like the planes (scale, block, row): flushed as 64-byte pieces
     constexpr int NBLK = CHUNKW / 32;
-    __shared__ __align__(16) uint32_t stage[3][NBLK][16];
+    constexpr int STG = 8;  // rows staged per flush
+    __shared__ __align__(16) uint32_t stage[3][NBLK][STG];
 
     const int tid = threadIdx.x;
     const int f = blockIdx.z;
@@ -180,32 +183,30 @@ __global__ __launch_bounds__(TPB) void k_gray_thresh3(const uint8_t* __restrict_
     // vertical running sums, two 16-bit fields per word (at most 23 * 255 per field)
     uint32_t V0[4] = {0, 0, 0, 0}, V1[4] = {0, 0, 0, 0}, V2[4] = {0, 0, 0, 0};
 
-    for (int i = tid; i < 3 * NBLK * 16; i += TPB) (&stage[0][0][0])[i] = 0u;
+    for (int i = tid; i < 3 * NBLK * STG; i += TPB) (&stage[0][0][0])[i] = 0u;
     const size_t perPlane = plane_words(H, WS);
     uint32_t* const fplanes = planes + (size_t)f * 3 * perPlane;
     const int bx0 = cx0 >> 5;  // first plane block of this strip (CHUNKW is a multiple of 32)
-    // write rows [16 hb, 16 hb + 16) of the strip's blocks to the three planes
-    auto flush = [&](int hb) {
+    // write rows [STG g, STG g + STG) of the strip's blocks to the three planes
+    auto flush = [&](int g) {
         wave_lds_sync();
-        for (int i = tid; i < 3 * NBLK * 4; i += TPB) {
-            const int sc = i / (NBLK * 4), rem = i - sc * (NBLK * 4), blk = rem >> 2, q = rem & 3;
+        constexpr int Q = STG / 4;  // 16-byte pieces per block and scale
+        for (int i = tid; i < 3 * NBLK * Q; i += TPB) {
+            const int sc = i / (NBLK * Q), rem = i - sc * (NBLK * Q), blk = rem / Q, q = rem % Q;
             if (bx0 + blk < WS) {
                 const uint4 v = *reinterpret_cast<const uint4*>(&stage[sc][blk][q * 4]);
-                uint32_t* dst = fplanes + (size_t)sc * perPlane + ((size_t)(hb >> 1) * WS + bx0 + blk) * 32 + (hb & 1) * 16 + q * 4;
+                const int row0 = g * STG;  // first row of the group
+                uint32_t* dst = fplanes + (size_t)sc * perPlane + ((size_t)(row0 >> 5) * WS + bx0 + blk) * 32 + (row0 & 31) + q * 4;
                 *reinterpret_cast<uint4*>(dst) = v;
             }
         }
         wave_lds_sync();
     };
-    uint8_t* const myStage = reinterpret_cast<uint8_t*>(&stage[0][0][0]) + (((tid - HALO / PX) >> 2) * 16) * 4 + ((tid - HALO / PX) & 3);
+    uint8_t* const myStage = reinterpret_cast<uint8_t*>(&stage[0][0][0]) + (((tid - HALO / PX) >> 2) * STG) * 4 + ((tid - HALO / PX) & 3);
 
     auto slot = [&](int row) { return (row + 4 * RING) % RING; };
     auto rowOffOf = [&](int row) { return frameOff + (size_t)min(max(row, 0), H - 1) * W; };
-
-    // warm-up: rows y0-RMAX-1 .. y0+RMAX-1 ; V_k = sum_{d=-r_k-1}^{r_k-1} g(y0+d)
-    for (int d = -RMAX - 1; d <= RMAX - 1; d++) {
-        uint2 g = load_gray8(in, C, W, rowOffOf(y0 + d), xbase, aligned);
-        *reinterpret_cast<uint2*>(&ring[slot(y0 + d)][PX * tid]) = g;
+    auto accumulate = [&](uint2 g, int d) {  // row y0 + d joins the warm-up sums V_k = sum_{d=-r_k-1}^{r_k-1} g(y0+d)
         uint32_t u[4];
         widen8(g, u);
         if (d >= -R0 - 1 && d <= R0 - 1) {
@@ -216,32 +217,48 @@ __global__ __launch_bounds__(TPB) void k_gray_thresh3(const uint8_t* __restrict_
 #pragma unroll
             for (int i = 0; i < 4; i++) V1[i] += u[i];
         }
-        {
 #pragma unroll
-            for (int i = 0; i < 4; i++) V2[i] += u[i];
-        }
+        for (int i = 0; i < 4; i++) V2[i] += u[i];
+    };
+
+    // warm-up: rows y0-RMAX-1 .. y0-1 go to the LDS ring, rows y0 .. y0+RMAX-1 to the delay line
+    for (int d = -RMAX - 1; d <= -1; d++) {
+        const uint2 g = load_gray8(in, C, W, rowOffOf(y0 + d), xbase, aligned);
+        *reinterpret_cast<uint2*>(&ring[slot(y0 + d)][PX * tid]) = g;
+        accumulate(g, d);
+    }
+    // dl[k] = row y + RMAX - k at the top of iteration y (dl[0] is the row loaded in that iteration)
+    uint2 dl[RMAX + 1];
+#pragma unroll
+    for (int k = RMAX; k >= 1; k--) {
+        dl[k] = load_gray8(in, C, W, rowOffOf(y0 + RMAX - k), xbase, aligned);
+        accumulate(dl[k], RMAX - k);
     }
 
     uint2 nxt = load_gray8(in, C, W, rowOffOf(y0 + RMAX), xbase, aligned);
     for (int y = y0; y < y1; y++) {
-        uint2 gin = nxt;
+        dl[0] = nxt;
         if (y + 1 < y1) nxt = load_gray8(in, C, W, rowOffOf(y + 1 + RMAX), xbase, aligned);
-        *reinterpret_cast<uint2*>(&ring[slot(y + RMAX)][PX * tid]) = gin;
 
         uint32_t a[4], b[4];
-        // largest window: incoming row is the one just loaded
-        widen8(gin, a);
+        // every window takes in the row r_k below the centre (delay line) and drops the row r_k + 1 above it (ring)
+        widen8(dl[0], a);
         widen8(*reinterpret_cast<const uint2*>(&ring[slot(y - R2 - 1)][PX * tid]), b);
 #pragma unroll
         for (int i = 0; i < 4; i++) V2[i] = V2[i] + a[i] - b[i];
-        widen8(*reinterpret_cast<const uint2*>(&ring[slot(y + R1)][PX * tid]), a);
+        widen8(dl[R2 - R1], a);
         widen8(*reinterpret_cast<const uint2*>(&ring[slot(y - R1 - 1)][PX * tid]), b);
 #pragma unroll
         for (int i = 0; i < 4; i++) V1[i] = V1[i] + a[i] - b[i];
-        widen8(*reinterpret_cast<const uint2*>(&ring[slot(y + R0)][PX * tid]), a);
+        widen8(dl[R2 - R0], a);
         widen8(*reinterpret_cast<const uint2*>(&ring[slot(y - R0 - 1)][PX * tid]), b);
 #pragma unroll
         for (int i = 0; i < 4; i++) V0[i] = V0[i] + a[i] - b[i];
+        const uint2 cen = dl[R2];  // row y
+        // row y replaces row y-RMAX-1 in the ring (read just above), and the delay line moves on
+        *reinterpret_cast<uint2*>(&ring[slot(y)][PX * tid]) = cen;
+#pragma unroll
+        for (int k = RMAX; k >= 1; k--) dl[k] = dl[k - 1];
 
         // exchange vertical sums (single wavefront: the barrier only orders this wave's LDS traffic)
         wave_lds_sync();
@@ -251,7 +268,6 @@ __global__ __launch_bounds__(TPB) void k_gray_thresh3(const uint8_t* __restrict_
         wave_lds_sync();
 
         if (inOut) {
-            const uint2 cen = *reinterpret_cast<const uint2*>(&ring[slot(y)][PX * tid]);
             uint32_t c[8], s0[8], s1[8], s2[8];
             unpack8(cen, c);
             hsum8<R0>(&xbuf[0][HALO], PX * tid, s0);
@@ -284,21 +300,21 @@ __global__ __launch_bounds__(TPB) void k_gray_thresh3(const uint8_t* __restrict_
             if (xbase == 0) keep &= 0xFEu;
             if (xbase + 7 >= W - 1) keep &= ~(1u << ((W - 1) - xbase)) & ((W - xbase) >= 8 ? 0xFFu : ((1u << (W - xbase)) - 1u));
             // stage this row's three bytes; bytes of columns >= W are never written and stay zero
-            uint8_t* q = myStage + (y & 15) * 4;
+            uint8_t* q = myStage + (y & (STG - 1)) * 4;
             q[0] = (uint8_t)(pm0 & keep);
-            q[NBLK * 64] = (uint8_t)(pm1 & keep);
-            q[2 * NBLK * 64] = (uint8_t)(pm2 & keep);
+            q[NBLK * STG * 4] = (uint8_t)(pm1 & keep);
+            q[2 * NBLK * STG * 4] = (uint8_t)(pm2 & keep);
         }
-        if ((y & 15) == 15) flush(y >> 4);
+        if ((y & (STG - 1)) == STG - 1) flush(y / STG);
     }
     // the band that ends the image also writes the zero rows that pad the last block row
     if (y1 == H) {
         for (int yy = H; yy < plane_hb(H) * 32; yy++) {
             if (inOut) {
-                uint8_t* q = myStage + (yy & 15) * 4;
-                q[0] = 0; q[NBLK * 64] = 0; q[2 * NBLK * 64] = 0;
+                uint8_t* q = myStage + (yy & (STG - 1)) * 4;
+                q[0] = 0; q[NBLK * STG * 4] = 0; q[2 * NBLK * STG * 4] = 0;
             }
-            if ((yy & 15) == 15) flush(yy >> 4);
+            if ((yy & (STG - 1)) == STG - 1) flush(yy / STG);
         }
     }
 }
