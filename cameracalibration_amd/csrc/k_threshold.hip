@@ -113,22 +113,24 @@ __device__ __forceinline__ void widen8(uint2 v, uint32_t o[4]) {
 }
 
 // Sliding horizontal sum of radius R over the exchanged vertical sums.
-// xb points at this scale's row of u16 sums; base = PX*lane.  The values come in with 16-byte reads on a
-// 16-byte lane stride (conflict-free); 4-byte reads on that stride would hit every bank four times.
+// The exchange buffer of one scale is laid out by word: word j (two sums) of every lane is contiguous,
+// xb[j * XROW + XPAD + lane], so that whichever word offset a lane reads from its neighbours, the 64 lanes
+// of the instruction touch 64 consecutive words (no bank conflicts; a 16-byte lane stride read 4 bytes at a
+// time hits every bank four times, and that made this kernel LDS-bound).
+constexpr int XPAD = 4;             // lanes of slack on either side of a word row
+constexpr int XROW = TPB + 2 * XPAD;
 template <int R>
-__device__ __forceinline__ void hsum8(const uint16_t* xb, int base, uint32_t out[8]) {
-    // window of pixel i covers [base+i-R, base+i+R]; gather [base-LO, base+8+LO) with LO a multiple of 8
-    constexpr int LO = ((R + 7) / 8) * 8;
-    constexpr int N = 8 + 2 * LO;  // values fetched
+__device__ __forceinline__ void hsum8(const uint32_t* xb, int lane, uint32_t out[8]) {
+    // window of pixel i covers values [i-R, i+R] relative to the lane's first; fetch words [-LO/2, 4+LO/2)
+    constexpr int LO = (R + 1) & ~1;  // even offset >= R
+    constexpr int N = 8 + 2 * LO;     // values fetched
     uint32_t v[N];
-    const uint4* p = reinterpret_cast<const uint4*>(xb + base - LO);
 #pragma unroll
-    for (int i = 0; i < N / 8; i++) {
-        const uint4 w = p[i];
-        v[8 * i + 0] = w.x & 0xFFFFu; v[8 * i + 1] = w.x >> 16;
-        v[8 * i + 2] = w.y & 0xFFFFu; v[8 * i + 3] = w.y >> 16;
-        v[8 * i + 4] = w.z & 0xFFFFu; v[8 * i + 5] = w.z >> 16;
-        v[8 * i + 6] = w.w & 0xFFFFu; v[8 * i + 7] = w.w >> 16;
+    for (int i = 0; i < N / 2; i++) {
+        const int d = i - LO / 2;  // word offset from the lane's first word: lane + (d >> 2), word d & 3
+        const uint32_t w = xb[(d & 3) * XROW + XPAD + lane + (d >> 2)];
+        v[2 * i] = w & 0xFFFFu;
+        v[2 * i + 1] = w >> 16;
     }
     uint32_t s = 0;
 #pragma unroll
@@ -161,7 +163,7 @@ __global__ __launch_bounds__(TPB) void k_gray_thresh3(const uint8_t* __restrict_
     constexpr int RING = RMAX + 1;  // rows y-1 .. y-rmax-1; rows y .. y+rmax sit in the register delay line
     static_assert(R0 <= R1 && R1 <= R2 && R2 <= HALO - 1, "radii must be sorted and fit the halo");
     __shared__ __align__(16) uint8_t ring[RING][ROWPX];
-    __shared__ __align__(16) uint16_t xbuf[3][ROWPX + 2 * HALO];  // HALO columns of slack on both sides (edge lanes read there, unused)
+    __shared__ uint32_t xbuf[3][4 * XROW];  // vertical sums of one row, by word (hsum8)
     // 16 rows of plane bits of this strip, laid out like the planes (scale, block, row): flushed as 64-byte pieces
     constexpr int NBLK = CHUNKW / 32;
     constexpr int STG = 8;  // rows staged per flush
@@ -262,17 +264,20 @@ __global__ __launch_bounds__(TPB) void k_gray_thresh3(const uint8_t* __restrict_
 
         // exchange vertical sums (single wavefront: the barrier only orders this wave's LDS traffic)
         wave_lds_sync();
-        *reinterpret_cast<uint4*>(&xbuf[0][HALO + PX * tid]) = make_uint4(V0[0], V0[1], V0[2], V0[3]);
-        *reinterpret_cast<uint4*>(&xbuf[1][HALO + PX * tid]) = make_uint4(V1[0], V1[1], V1[2], V1[3]);
-        *reinterpret_cast<uint4*>(&xbuf[2][HALO + PX * tid]) = make_uint4(V2[0], V2[1], V2[2], V2[3]);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            xbuf[0][j * XROW + XPAD + tid] = V0[j];
+            xbuf[1][j * XROW + XPAD + tid] = V1[j];
+            xbuf[2][j * XROW + XPAD + tid] = V2[j];
+        }
         wave_lds_sync();
 
         if (inOut) {
             uint32_t c[8], s0[8], s1[8], s2[8];
             unpack8(cen, c);
-            hsum8<R0>(&xbuf[0][HALO], PX * tid, s0);
-            hsum8<R1>(&xbuf[1][HALO], PX * tid, s1);
-            hsum8<R2>(&xbuf[2][HALO], PX * tid, s2);
+            hsum8<R0>(xbuf[0], tid, s0);
+            hsum8<R1>(xbuf[1], tid, s1);
+            hsum8<R2>(xbuf[2], tid, s2);
             // one byte per scale, bit i = pixel xbase+i
             const uint32_t pm0 = thresh_bits<K0>(s0, c, c0), pm1 = thresh_bits<K1>(s1, c, c1), pm2 = thresh_bits<K2>(s2, c, c2);
             const size_t off = frameOff + (size_t)y * W + xbase;
