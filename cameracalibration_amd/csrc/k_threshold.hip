@@ -52,37 +52,56 @@ __device__ __forceinline__ uint32_t luma_dot(uint32_t p) {
     return ((hi << 8) + lo) >> 15;
 }
 
+// The 24 (C == 3) or 8 (C == 1) input bytes of columns xbase..xbase+7 of one row, as loaded; converting them
+// to gray is a separate step so that several rows of loads can be in flight per wave (a wave with one row in
+// flight caps the whole chip at ~2.7 TB/s: 14 waves x 1.5 KB per CU per memory latency).
+struct RawRow { uint2 a, b, c; };
+
+__device__ __forceinline__ RawRow issue_row(const uint8_t* __restrict__ in, int C, int W, size_t rowOff, int xbase) {
+    // W is a multiple of 8 and so is xbase: a group is inside the image or entirely outside, where
+    // BORDER_REPLICATE makes all 8 values the edge pixel of the nearest inside group
+    const int xc = min(max(xbase, 0), W - 8);
+    RawRow r;
+    if (C == 3) {
+        const uint2* p = reinterpret_cast<const uint2*>(in + (rowOff + (size_t)xc) * 3);
+        r.a = p[0]; r.b = p[1]; r.c = p[2];
+    } else {
+        r.a = *reinterpret_cast<const uint2*>(in + rowOff + (size_t)xc);
+        r.b = r.c = make_uint2(0, 0);
+    }
+    return r;
+}
+
+__device__ __forceinline__ uint2 gray_of(const RawRow& q, int C, int W, int xbase) {
+    uint2 r;
+    if (C == 3) {
+        const uint2 a = q.a, b = q.b, c = q.c;
+        uint32_t g[8];
+        // pixel i starts at byte 3 i of the 24 bytes a.x a.y b.x b.y c.x c.y
+        g[0] = luma_dot(a.x);
+        g[1] = luma_dot(__builtin_amdgcn_alignbyte(a.y, a.x, 3));
+        g[2] = luma_dot(__builtin_amdgcn_alignbyte(b.x, a.y, 2));
+        g[3] = luma_dot(__builtin_amdgcn_alignbyte(b.y, b.x, 1));
+        g[4] = luma_dot(b.y);
+        g[5] = luma_dot(__builtin_amdgcn_alignbyte(c.x, b.y, 3));
+        g[6] = luma_dot(__builtin_amdgcn_alignbyte(c.y, c.x, 2));
+        g[7] = luma_dot(c.y >> 8);
+        r.x = g[0] | (g[1] << 8) | (g[2] << 16) | (g[3] << 24);
+        r.y = g[4] | (g[5] << 8) | (g[6] << 16) | (g[7] << 24);
+    } else {
+        r = q.a;
+    }
+    if (xbase < 0) r.x = r.y = (r.x & 255u) * 0x01010101u;
+    else if (xbase >= W) r.x = r.y = (r.y >> 24) * 0x01010101u;
+    return r;
+}
+
 // Load the 8 gray values of columns xbase..xbase+7 (clamped to the image) of
 // row `row` (already clamped) of frame f, converting from BGR when C == 3.
 __device__ __forceinline__ uint2 load_gray8(const uint8_t* __restrict__ in, int C, int W, size_t rowOff,
                                             int xbase, bool aligned) {
+    if (aligned) return gray_of(issue_row(in, C, W, rowOff, xbase), C, W, xbase);
     uint32_t g[8];
-    if (aligned) {
-        // W is a multiple of 8 and so is xbase: a group is inside the image or entirely outside, where
-        // BORDER_REPLICATE makes all 8 values the edge pixel of the nearest inside group
-        const int xc = min(max(xbase, 0), W - 8);
-        uint2 r;
-        if (C == 3) {
-            const uint2* p = reinterpret_cast<const uint2*>(in + (rowOff + (size_t)xc) * 3);
-            const uint2 a = p[0], b = p[1], c = p[2];
-            // pixel i starts at byte 3 i of the 24 bytes a.x a.y b.x b.y c.x c.y
-            g[0] = luma_dot(a.x);
-            g[1] = luma_dot(__builtin_amdgcn_alignbyte(a.y, a.x, 3));
-            g[2] = luma_dot(__builtin_amdgcn_alignbyte(b.x, a.y, 2));
-            g[3] = luma_dot(__builtin_amdgcn_alignbyte(b.y, b.x, 1));
-            g[4] = luma_dot(b.y);
-            g[5] = luma_dot(__builtin_amdgcn_alignbyte(c.x, b.y, 3));
-            g[6] = luma_dot(__builtin_amdgcn_alignbyte(c.y, c.x, 2));
-            g[7] = luma_dot(c.y >> 8);
-            r.x = g[0] | (g[1] << 8) | (g[2] << 16) | (g[3] << 24);
-            r.y = g[4] | (g[5] << 8) | (g[6] << 16) | (g[7] << 24);
-        } else {
-            r = *reinterpret_cast<const uint2*>(in + rowOff + (size_t)xc);
-        }
-        if (xbase < 0) r.x = r.y = (r.x & 255u) * 0x01010101u;
-        else if (xbase >= W) r.x = r.y = (r.y >> 24) * 0x01010101u;
-        return r;
-    }
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         int x = min(max(xbase + i, 0), W - 1);
@@ -237,10 +256,17 @@ __global__ __launch_bounds__(TPB) void k_gray_thresh3(const uint8_t* __restrict_
         accumulate(dl[k], RMAX - k);
     }
 
-    uint2 nxt = load_gray8(in, C, W, rowOffOf(y0 + RMAX), xbase, aligned);
+    // rows y+RMAX .. y+RMAX+AHEAD-1 are in flight at the top of iteration y (aligned frames; otherwise the
+    // slow per-pixel loader fetches the row when it is needed)
+    constexpr int AHEAD = 3;
+    RawRow pend[AHEAD];
+#pragma unroll
+    for (int k = 0; k < AHEAD; k++) pend[k] = issue_row(in, C, W, rowOffOf(y0 + RMAX + k), aligned ? xbase : 0);
     for (int y = y0; y < y1; y++) {
-        dl[0] = nxt;
-        if (y + 1 < y1) nxt = load_gray8(in, C, W, rowOffOf(y + 1 + RMAX), xbase, aligned);
+        dl[0] = aligned ? gray_of(pend[0], C, W, xbase) : load_gray8(in, C, W, rowOffOf(y + RMAX), xbase, false);
+#pragma unroll
+        for (int k = 0; k + 1 < AHEAD; k++) pend[k] = pend[k + 1];
+        pend[AHEAD - 1] = issue_row(in, C, W, rowOffOf(y + RMAX + AHEAD), aligned ? xbase : 0);
 
         uint32_t a[4], b[4];
         // every window takes in the row r_k below the centre (delay line) and drops the row r_k + 1 above it (ring)
