@@ -701,33 +701,30 @@ __global__ __launch_bounds__(64) void k_trace_decide(const uint32_t* __restrict_
                     s ^= 4;  // now: direction towards the pixel we came from, the forward successor
                 }
                 newState = state0;
-            } else if (!bw) {
-                // forward: from (P, s) sweep counter-clockwise from s + 1
-                const uint32_t rot = ((m >> (s + 1)) | (m << (7 - s))) & 0xFFu;  // bit j <-> direction s+1+j
-                const int k = __ffs(rot);  // 1..8: m always holds the neighbour we came from
-                const int d = (s + k) & 7;
-                if ((!isHole || s + k >= 9) && cy * W + cx < startKey) abort = true;  // smaller key: not canonical
-                if ((count & (kCkStride - 1)) == 0 && count) myCk[min(count / kCkStride, kCkMax - 1)] = pack_state(cx, cy, s);
-                count++;
-                cx += fast_dx(d);
-                cy += fast_dy(d);
-                s = d ^ 4;
-                newState = pack_state(cx, cy, s);
             } else {
-                // backward: at pixel P whose forward successor lies in direction s; its predecessor is the first
-                // foreground neighbour clockwise from s - 1.  Bit-reverse the mask so clockwise = increasing bits.
-                const uint32_t mr = __brev(m) >> 24;  // bit b <-> direction 7 - b
-                const int b0 = (8 - s) & 7;           // bit of direction s - 1
-                const uint32_t rot = ((mr >> b0) | (mr << (8 - b0))) & 0xFFu;
-                const int j = __ffs(rot) - 1;         // zeros swept: directions s-1 ... s-j
-                const int p = (s - 1 - j) & 7;        // predecessor direction
-                if ((!isHole || (s >= 1 && s <= j)) && cy * W + cx < startKey) abort = true;
+                // One step, forward (T) or backward (T^-1), on one code path (the two lanes of a pair would
+                // otherwise serialise two branches every iteration).
+                //   forward : from (P, s) sweep counter-clockwise from s + 1 to the first foreground neighbour d;
+                //             the pixel counted is P, the new state is (P + d, d + 4).
+                //   backward: at pixel P whose forward successor lies in direction s, the predecessor p is the
+                //             first foreground neighbour clockwise from s - 1; bit-reversing the mask turns
+                //             clockwise into increasing bit numbers.  The state completed is (P, p).
+                const uint32_t mm = bw ? (__brev(m) >> 24) : m;      // backward: bit b <-> direction 7 - b
+                const int b0 = bw ? ((8 - s) & 7) : ((s + 1) & 7);    // first bit looked at
+                const uint32_t rot = ((mm >> b0) | (mm << (8 - b0))) & 0xFFu;
+                const int j = __ffs(rot) - 1;                          // zeros swept (m always holds a neighbour)
+                const int q = bw ? ((s - 1 - j) & 7) : ((s + 1 + j) & 7);  // direction found: p or d
+                // the sweep passed the east neighbour: forward s + 1 + j >= 9, backward 1 <= s <= j
+                const bool east = bw ? (s >= 1 && s <= j) : (s + j >= 8);
+                if ((!isHole || east) && cy * W + cx < startKey) abort = true;  // smaller key: not canonical
+                const uint32_t here = pack_state(cx, cy, bw ? q : s);  // forward: A_count, backward: B_(count+1)
+                if (!bw && (count & (kCkStride - 1)) == 0 && count) myCk[min(count / kCkStride, kCkMax - 1)] = here;
                 count++;
-                newState = pack_state(cx, cy, p);     // the completed state B_count
-                if ((count & (kCkStride - 1)) == 0) myCk[min(count / kCkStride, kCkMax - 1)] = newState;
-                cx += fast_dx(p);
-                cy += fast_dy(p);
-                s = p ^ 4;
+                if (bw && (count & (kCkStride - 1)) == 0) myCk[min(count / kCkStride, kCkMax - 1)] = here;
+                cx += fast_dx(q);
+                cy += fast_dy(q);
+                s = q ^ 4;
+                newState = bw ? here : pack_state(cx, cy, s);
             }
         }
         // ---- the pair compares notes (both lanes of a pair are active or idle together) ----
