@@ -341,11 +341,11 @@ int camsync_create(camsync_ctx** out, int device, int max_h, int max_w, int max_
     HIPCHK(c, dalloc(&b.cand, b.candCap));
     HIPCHK(c, dalloc(&b.candLong, b.candCap));
     // (+ the blocks the persistent border-follower waves reserve and may leave partly unused)
-    b.contourCap = (unsigned)std::min<size_t>(B * 4096 + (size_t)kTraceWaves * 32, 0x7FFFFFFFu);
+    b.contourCap = (unsigned)std::min<size_t>(B * 4096 + (size_t)(kTraceWaves + 8192) * 32, 0x7FFFFFFFu);
     HIPCHK(c, dalloc(&b.contours, b.contourCap));
-    b.poolCap = (unsigned)std::min<size_t>(B * (size_t)262144 + (size_t)kTraceWaves * 16384, 0x7FFFFFFFu);
+    b.poolCap = (unsigned)std::min<size_t>(B * (size_t)262144 + (size_t)kTraceWaves * 16384 + (size_t)8192 * 2048, 0x7FFFFFFFu);
     HIPCHK(c, dalloc(&b.pool, b.poolCap));
-    b.taskCap = (unsigned)std::min<size_t>((size_t)b.contourCap * 2 + b.poolCap / kCkStride + (size_t)kTraceWaves * 128, 0x7FFFFFFFu);
+    b.taskCap = (unsigned)std::min<size_t>((size_t)b.contourCap * 2 + b.poolCap / kCkStride + (size_t)kTraceWaves * 128 + (size_t)8192 * 32, 0x7FFFFFFFu);
     HIPCHK(c, dalloc(&b.tasks, b.taskCap));
     HIPCHK(c, dalloc(&b.ckpt, (size_t)kTraceWaves * 32 * 2 * kCkMax));
     HIPCHK(c, dalloc(&b.quads, B * kQuadCap));

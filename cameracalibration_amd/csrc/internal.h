@@ -99,7 +99,8 @@ struct Counters {
     unsigned int qDecide;   // work-queue heads of the long-border kernels (lanes fetch their next border here)
     unsigned int qStore;
     unsigned int nTasks;    // store tasks appended by the decide passes
-    unsigned int pad[3];
+    unsigned int qShort;    // work-queue head of the short-border kernel
+    unsigned int pad[2];
 };
 
 struct DetBuffers {

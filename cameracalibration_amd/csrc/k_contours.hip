@@ -401,61 +401,6 @@ __device__ __forceinline__ unsigned int reserve_tasks(unsigned int n, unsigned i
     return t;
 }
 
-constexpr int kShortBudget = 48;
-
-__global__ __launch_bounds__(256) void k_trace_short(const uint32_t* __restrict__ planes, DetCfg cfg,
-                                                     const uint64_t* __restrict__ cand, unsigned int candCap,
-                                                     uint64_t* __restrict__ candLong, ContourRec* __restrict__ contours,
-                                                     unsigned int contourCap, unsigned int poolCap,
-                                                     StoreTask* __restrict__ tasks, unsigned int taskCap, Counters* __restrict__ ctr) {
-    const unsigned int n = min(ctr->nCand, candCap);
-    const int H = cfg.H, W = cfg.W, WS = cfg.WS, S = cfg.nScales;
-    const size_t perPlane = plane_words(H, WS);
-    const unsigned int stride = gridDim.x * blockDim.x;
-    // all lanes of a wave run the same number of rounds so the wave-wide append below is convergent
-    for (unsigned int i0 = blockIdx.x * blockDim.x; i0 < n; i0 += stride) {
-        const unsigned int i = i0 + threadIdx.x;
-        uint64_t c = 0;
-        int res = 0;
-        if (i < n) c = cand[i];
-        if (i < n && c != ~0ull) {  // ~0 marks a staging slot that was never filled
-            const uint32_t pos = (uint32_t)(c & 0xFFFFFFFFull);
-            const int sc = (int)((c >> 36) & 7u);
-            const bool hole = (c >> 39) & 1u;
-            const uint32_t f = (uint32_t)(c >> 40);
-            const uint32_t* plane = planes + ((size_t)f * S + sc) * perPlane;
-            res = probe_border(plane, WS, W, pos % W, pos / W, hole, kShortBudget);
-        }
-        if (res >= cfg.minPerim && res <= cfg.maxPerim) {
-            // a border this short is one store task from its fresh start
-            const unsigned int off = emit_contour(c, res, contours, contourCap, poolCap, ctr);
-            const unsigned int t = off != ~0u ? reserve_tasks(1, taskCap, ctr) : ~0u;
-            if (t != ~0u) {
-                const uint32_t pos = (uint32_t)(c & 0xFFFFFFFFull);
-                StoreTask k;
-                k.plane = (uint32_t)(c >> 40) * S + (uint32_t)((c >> 36) & 7u);
-                k.state = pack_state(pos % W, pos / W, 8 + (int)((c >> 39) & 1u));
-                k.dst = off;
-                k.count = (uint32_t)res;
-                tasks[t] = k;
-            }
-        }
-        const bool undecided = res == -1;
-        const unsigned long long bal = __ballot(undecided);
-        if (bal) {
-            const int lane = threadIdx.x & 63;
-            unsigned int wbase = 0;
-            if (lane == 0) wbase = atomicAdd(&ctr->nLong, (unsigned int)__popcll(bal));
-            wbase = __shfl(wbase, 0, 64);
-            if (undecided) {
-                const unsigned int o = wbase + (unsigned int)__popcll(bal & ((1ull << lane) - 1ull));
-                if (o < candCap) candLong[o] = c;
-                else atomicOr(&ctr->overflow, 1u);
-            }
-        }
-    }
-}
-
 // ---- long borders -------------------------------------------------------------------------------
 // Border following is a walk on states (pixel, direction to the predecessor): the successor T(P, s) is
 // found by sweeping counter-clockwise from s + 1 to the first foreground neighbour d, giving (P + d, d + 4);
@@ -622,6 +567,158 @@ __device__ __forceinline__ void mark_empty_tasks(StoreTask* __restrict__ tasks, 
         k.plane = 0; k.state = 0; k.dst = 0; k.count = 0;
         tasks[i] = k;
     }
+}
+
+// ---- short borders ------------------------------------------------------------------------------
+// Most start candidates are noise specks or false starts that are decided within a handful of steps, a few
+// per cent need the whole budget.  Lanes therefore work independently: a lane that has decided its candidate
+// takes the next one from the wave's batch, instead of the wave waiting for its slowest lane every round
+// (which made 94 % of the wave-steps idle).  Each step advances the candidate's forward tracer and, in
+// lock-step, a tracer walking the border the other way round; both look for a crack with a smaller key.
+constexpr int kShortBudget = 48;
+constexpr unsigned int kShortBatch = 256, kShortPoolBlock = 2048, kLongStage = 64;
+
+__global__ __launch_bounds__(256) void k_trace_short(const uint32_t* __restrict__ planes, DetCfg cfg,
+                                                     const uint64_t* __restrict__ cand, unsigned int candCap,
+                                                     uint64_t* __restrict__ candLong, ContourRec* __restrict__ contours,
+                                                     unsigned int contourCap, unsigned int poolCap,
+                                                     StoreTask* __restrict__ tasks, unsigned int taskCap, Counters* __restrict__ ctr) {
+    __shared__ uint64_t s_long[4][kLongStage];
+    const int lane = threadIdx.x & 63;
+    uint64_t* const stage = s_long[threadIdx.x >> 6];
+    unsigned int staged = 0;  // uniform
+    const unsigned int n = min(ctr->nCand, candCap);
+    const int H = cfg.H, W = cfg.W, WS = cfg.WS, S = cfg.nScales;
+    const size_t perPlane = plane_words(H, WS);
+    (void)H;
+
+    auto flush_long = [&]() {
+        if (staged) {
+            unsigned int g = 0;
+            if (lane == 0) g = atomicAdd(&ctr->nLong, staged);
+            g = __builtin_amdgcn_readfirstlane(g);
+            if (g + staged > candCap) {
+                if (lane == 0) atomicOr(&ctr->overflow, 1u);
+            } else {
+                for (unsigned int k = lane; k < staged; k += 64) candLong[g + k] = stage[k];
+            }
+            staged = 0;
+        }
+    };
+
+    WaveQueue queue;
+    WaveAlloc poolA, slotA, taskA;
+    bool active = false, exhausted = false, isHole = false, bwActive = false;
+    uint64_t c = 0;
+    int count = 0, startKey = 0;
+    const uint32_t* plane = planes;
+    Tracer<false> fw;
+    Tracer<true> bw;
+    fw.x0 = fw.y0 = fw.x1 = fw.y1 = fw.cx = fw.cy = 1; fw.s = 0; fw.m = 0;
+    bw.x0 = bw.y0 = bw.x1 = bw.y1 = bw.cx = bw.cy = 1; bw.s = 0; bw.m = 0;
+
+    for (;;) {
+        // res: -2 keep going, -1 budget exhausted (long list), 0 drop, > 0 closed with that many points
+        int res = -2;
+        {
+            const bool need = !active && !exhausted;
+            const unsigned int i = queue.pop<1>(need, &ctr->qShort, n, kShortBatch, lane);
+            if (need) {
+                if (i != ~0u) {
+                    c = cand[i];
+                    if (c != ~0ull) {  // ~0 would mark a slot that was never filled
+                        const uint32_t pos = (uint32_t)(c & 0xFFFFFFFFull);
+                        plane = planes + ((size_t)(uint32_t)(c >> 40) * S + (int)((c >> 36) & 7u)) * perPlane;
+                        isHole = (c >> 39) & 1u;
+                        const int x0 = (int)(pos % W), y0 = (int)(pos / W);
+                        startKey = y0 * W + x0;
+                        count = 0;
+                        active = true;
+                        if (!fw.init(plane, WS, x0, y0, isHole)) res = 1;  // a single pixel
+                        else bwActive = bw.init(plane, WS, x0, y0, isHole);
+                    }
+                } else if (queue.empty()) {
+                    exhausted = true;
+                }
+            }
+        }
+        if (!__any(active)) {
+            if (__all(exhausted)) break;
+            continue;
+        }
+        if (active && res == -2) {
+            int px, py;
+            bool east;
+            const bool closed = fw.step(plane, WS, px, py, east);
+            if ((!isHole || east) && py * W + px < startKey) {
+                res = 0;
+            } else {
+                count++;
+                if (closed) res = count;
+                else if (count >= kShortBudget) res = -1;
+                else if (bwActive) {
+                    const bool bclosed = bw.step(plane, WS, px, py, east);
+                    if ((!isHole || east) && py * W + px < startKey) res = 0;
+                    if (bclosed) bwActive = false;
+                }
+            }
+        }
+        // ---- undecided candidates go to the long list through the wave's staging list ----
+        {
+            const bool und = active && res == -1;
+            const unsigned long long bal = __ballot(und);
+            if (bal) {
+                const unsigned int cnt = (unsigned int)__popcll(bal);
+                if (staged + cnt > kLongStage) flush_long();
+                if (und) stage[staged + (unsigned int)__popcll(bal & ((1ull << lane) - 1ull))] = c;
+                staged += cnt;
+            }
+        }
+        // ---- borders that closed within the perimeter bounds: space from the wave's blocks, one store task ----
+        const bool accept = active && res >= cfg.minPerim && res <= cfg.maxPerim;
+        unsigned int myOff = ~0u, mySlot = ~0u, myTask = ~0u;
+        unsigned long long am = __ballot(accept);
+        while (am) {
+            const int l = __ffsll((long long)am) - 1;
+            am &= am - 1;
+            const unsigned int len = (unsigned int)__shfl(res, l, 64);
+            uint2 left;
+            const unsigned int off = poolA.take(len, kShortPoolBlock, &ctr->nPool, poolCap, 4u, ctr, lane, left);
+            const unsigned int slot = slotA.take(1, kSlotBlock, &ctr->nContours, contourCap, 2u, ctr, lane, left);
+            const unsigned int t0 = taskA.take(1, kSlotBlock, &ctr->nTasks, taskCap, 64u, ctr, lane, left);
+            if (lane == l && off != ~0u && slot != ~0u && t0 != ~0u) {
+                myOff = off;
+                mySlot = slot;
+                myTask = t0;
+            }
+        }
+        if (active && res != -2) {
+            active = false;
+            if (accept && myOff != ~0u) {
+                const uint32_t pos = (uint32_t)(c & 0xFFFFFFFFull);
+                ContourRec r;
+                r.frame = (uint32_t)(c >> 40);
+                r.pos = pos;
+                r.len = (uint32_t)res;
+                r.off = myOff;
+                r.scale = (uint16_t)((c >> 36) & 7u);
+                r.hole = isHole ? 1 : 0;
+                r.scanKey = pos + (isHole ? 1u : 0u);
+                contours[mySlot] = r;
+                // a border this short is one store task from its fresh start
+                StoreTask k;
+                k.plane = r.frame * S + r.scale;
+                k.state = pack_state(pos % W, pos / W, 8 + (isHole ? 1 : 0));
+                k.dst = myOff;
+                k.count = (uint32_t)res;
+                tasks[myTask] = k;
+            }
+        }
+    }
+    flush_long();
+    // entries reserved but never used must read as empty
+    mark_empty_contours(contours, slotA.cur, slotA.end, lane);
+    mark_empty_tasks(tasks, taskA.cur, taskA.end, lane);
 }
 
 // Decide the long candidates (canonical start? length within bounds?), reserve pool space and cut the accepted
