@@ -55,6 +55,7 @@ __global__ __launch_bounds__(64) void k_identify(const uint8_t* __restrict__ gra
     __shared__ uint8_t s_img[kMaxSide * kMaxSide];
     __shared__ int s_hist[256];
     __shared__ int s_thr;
+    __shared__ double s_q1[256], s_mu1[256];
 
     const int lane = threadIdx.x;
     const int f = blockIdx.y;
@@ -164,27 +165,62 @@ __global__ __launch_bounds__(64) void k_identify(const uint8_t* __restrict__ gra
         if (stddev < cfg.minOtsuStdDev) {
             bitsMask = (mean > 127) ? ~0ull : 0ull;
         } else {
+            // getThreshVal_Otsu_8u.  Its loop carries (q1, mu1) from bin to bin through a division, so that part
+            // stays sequential on one lane, in the reference's operation order; everything that only feeds the
+            // arg-max (q2, mu2, sigma) is evaluated afterwards by all lanes.  Bins before the first and after
+            // the last occupied one cannot change the result (q1 is 0 resp. ~1 there: the loop `continue`s) and
+            // are skipped; the histogram moments are sums of integers, exact in any order.
+            const int N = S * S;
+            const double scale = 1. / N;
+            int h4[4];
+            long long part = 0;
+            bool any = false;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                h4[k] = s_hist[4 * lane + k];
+                part += (long long)(4 * lane + k) * h4[k];
+                any = any || h4[k] != 0;
+            }
+            const unsigned long long occ = __ballot(any);
+            const int firstBin = 4 * (__ffsll((long long)occ) - 1), lastBin = 4 * (63 - __clzll(occ)) + 3;
+            const double mu = (double)wave_sum_ll(part) * scale;
             if (lane == 0) {
-                // getThreshVal_Otsu_8u
-                const int N = S * S;
-                double mu = 0;
-                const double scale = 1. / N;
-                for (int i = 0; i < 256; i++) mu += i * (double)s_hist[i];
-                mu *= scale;
-                double mu1 = 0, q1 = 0, max_sigma = 0, max_val = 0;
-                for (int i = 0; i < 256; i++) {
+                double mu1 = 0, q1 = 0;
+                for (int i = firstBin; i <= lastBin; i++) {
                     const double p_i = s_hist[i] * scale;
                     mu1 *= q1;
                     q1 += p_i;
                     const double q2 = 1. - q1;
-                    if (fmin(q1, q2) < 1.1920928955078125e-07 || fmax(q1, q2) > 1. - 1.1920928955078125e-07) continue;
-                    mu1 = (mu1 + i * p_i) / q1;
-                    const double mu2 = (mu - q1 * mu1) / q2;
-                    const double sigma = q1 * q2 * (mu1 - mu2) * (mu1 - mu2);
-                    if (sigma > max_sigma) { max_sigma = sigma; max_val = i; }
+                    const bool skip = fmin(q1, q2) < 1.1920928955078125e-07 || fmax(q1, q2) > 1. - 1.1920928955078125e-07;
+                    if (!skip) mu1 = (mu1 + i * p_i) / q1;
+                    s_q1[i] = skip ? -1. : q1;
+                    s_mu1[i] = mu1;
                 }
-                s_thr = (int)max_val;
             }
+            __syncthreads();
+            double best = 0;
+            int bestBin = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int i = 4 * lane + k;
+                if (i >= firstBin && i <= lastBin) {
+                    const double q1 = s_q1[i];
+                    if (q1 >= 0) {
+                        const double mu1 = s_mu1[i], q2 = 1. - q1;
+                        const double mu2 = (mu - q1 * mu1) / q2;
+                        const double sigma = q1 * q2 * (mu1 - mu2) * (mu1 - mu2);
+                        if (sigma > best) { best = sigma; bestBin = i; }
+                    }
+                }
+            }
+            // first bin reaching the overall maximum (the reference keeps the earlier bin on ties: strict >)
+            double wmax = best;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) wmax = fmax(wmax, __shfl_xor(wmax, d, 64));
+            const unsigned long long who = __ballot(best == wmax && best > 0);
+            if (lane == 0) s_thr = 0;
+            __syncthreads();
+            if (who && lane == __ffsll((long long)who) - 1) s_thr = bestBin;
             __syncthreads();
             const int thr = s_thr;
             const int side = cell - 2 * cfg.cellMargin;
