@@ -49,9 +49,6 @@ __device__ __forceinline__ uint32_t rotate_code(uint32_t code, int n, int r) {
 __global__ __launch_bounds__(64) void k_identify(const uint8_t* __restrict__ gray, QuadRec* __restrict__ quads,
                                                  const int* __restrict__ qcount, const uint16_t* __restrict__ dict,
                                                  DetCfg cfg) {
-    __shared__ double s_a[8][9];
-    __shared__ double s_mi[9];
-    __shared__ int s_ok;
     __shared__ uint8_t s_img[kMaxSide * kMaxSide];
     __shared__ int s_hist[256];
     __shared__ int s_thr;
@@ -69,64 +66,95 @@ __global__ __launch_bounds__(64) void k_identify(const uint8_t* __restrict__ gra
     for (int qi = blockIdx.x; qi < nq; qi += gridDim.x) {
         __syncthreads();
         QuadRec* qr = &quads[(size_t)f * kQuadCap + qi];
-        if (lane == 0) {
-            // getPerspectiveTransform(corners -> (0,0),(S-1,0),(S-1,S-1),(0,S-1)) and its inverse
-            const double dstx[4] = {0, (double)(float)(S - 1), (double)(float)(S - 1), 0};
-            const double dsty[4] = {0, 0, (double)(float)(S - 1), (double)(float)(S - 1)};
-            for (int i = 0; i < 4; i++) {
-                const double sx = qr->c[2 * i], sy = qr->c[2 * i + 1], dx = dstx[i], dy = dsty[i];
-                s_a[i][0] = sx; s_a[i][1] = sy; s_a[i][2] = 1; s_a[i][3] = 0; s_a[i][4] = 0; s_a[i][5] = 0;
-                s_a[i][6] = -sx * dx; s_a[i][7] = -sy * dx; s_a[i][8] = dx;
-                s_a[i + 4][0] = 0; s_a[i + 4][1] = 0; s_a[i + 4][2] = 0; s_a[i + 4][3] = sx; s_a[i + 4][4] = sy; s_a[i + 4][5] = 1;
-                s_a[i + 4][6] = -sx * dy; s_a[i + 4][7] = -sy * dy; s_a[i + 4][8] = dy;
+        // getPerspectiveTransform(corners -> (0,0),(S-1,0),(S-1,S-1),(0,S-1)) and its inverse.
+        // The 8x9 system is eliminated with lane c holding column c in registers: every element update of the
+        // reference's row operations is independent, so the arithmetic (and hence the rounding of the sample
+        // positions) is the same as on one thread, without the serial trips through LDS.
+        double mi[9];
+        bool ok = true;
+        {
+            const double S1 = (double)(float)(S - 1);
+            double col[8];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const double sx = qr->c[2 * r], sy = qr->c[2 * r + 1];
+                const double dx = (r == 1 || r == 2) ? S1 : 0., dy = (r >= 2) ? S1 : 0.;
+                double top, bot;  // rows r and r + 4, column `lane`
+                switch (lane) {
+                    case 0: top = sx; bot = 0; break;
+                    case 1: top = sy; bot = 0; break;
+                    case 2: top = 1; bot = 0; break;
+                    case 3: top = 0; bot = sx; break;
+                    case 4: top = 0; bot = sy; break;
+                    case 5: top = 0; bot = 1; break;
+                    case 6: top = -sx * dx; bot = -sx * dy; break;
+                    case 7: top = -sy * dx; bot = -sy * dy; break;
+                    case 8: top = dx; bot = dy; break;
+                    default: top = 0; bot = 0; break;
+                }
+                col[r] = top;
+                col[r + 4] = bot;
             }
-            bool ok = true;
-            for (int i = 0; i < 8 && ok; i++) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                // partial pivoting on column i (held by lane i): first row with the largest magnitude
                 int k = i;
+                double big = fabs(col[i]);
+#pragma unroll
                 for (int j = i + 1; j < 8; j++)
-                    if (fabs(s_a[j][i]) > fabs(s_a[k][i])) k = j;
-                if (fabs(s_a[k][i]) < 2.220446049250313e-16) { ok = false; break; }
-                if (k != i)
-                    for (int j = i; j < 9; j++) { double t = s_a[i][j]; s_a[i][j] = s_a[k][j]; s_a[k][j] = t; }
-                const double d = -1 / s_a[i][i];
+                    if (fabs(col[j]) > big) { big = fabs(col[j]); k = j; }
+                k = __shfl(k, i, 64);
+                big = __shfl(big, i, 64);
+                if (big < 2.220446049250313e-16) { ok = false; break; }
+                // swap rows i and k
+                double rk = col[i];
+#pragma unroll
+                for (int j = i + 1; j < 8; j++) rk = (j == k) ? col[j] : rk;
+#pragma unroll
+                for (int j = i + 1; j < 8; j++) col[j] = (j == k) ? col[i] : col[j];
+                col[i] = rk;
+                const double d = -1 / __shfl(col[i], i, 64);
+#pragma unroll
                 for (int j = i + 1; j < 8; j++) {
-                    const double alpha = s_a[j][i] * d;
-                    for (int c = i + 1; c < 9; c++) s_a[j][c] += alpha * s_a[i][c];
+                    const double alpha = __shfl(col[j], i, 64) * d;
+                    if (lane > i) col[j] += alpha * col[i];
                 }
             }
-            double M[9];
             if (ok) {
                 double x[8];
+#pragma unroll
                 for (int i = 7; i >= 0; i--) {
-                    double s = s_a[i][8];
-                    for (int k = i + 1; k < 8; k++) s -= s_a[i][k] * x[k];
-                    x[i] = s / s_a[i][i];
+                    double sacc = __shfl(col[i], 8, 64);
+#pragma unroll
+                    for (int k = i + 1; k < 8; k++) sacc -= __shfl(col[i], k, 64) * x[k];
+                    x[i] = sacc / __shfl(col[i], i, 64);
                 }
-                for (int i = 0; i < 8; i++) M[i] = x[i];
-                M[8] = 1.0;
-                const double det = M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6]) +
-                                   M[2] * (M[3] * M[7] - M[4] * M[6]);
+                const double M8 = 1.0;
+                const double det = x[0] * (x[4] * M8 - x[5] * x[7]) - x[1] * (x[3] * M8 - x[5] * x[6]) +
+                                   x[2] * (x[3] * x[7] - x[4] * x[6]);
                 if (det == 0) ok = false;
                 else {
                     const double id = 1. / det;
-                    s_mi[0] = (M[4] * M[8] - M[5] * M[7]) * id;
-                    s_mi[1] = (M[2] * M[7] - M[1] * M[8]) * id;
-                    s_mi[2] = (M[1] * M[5] - M[2] * M[4]) * id;
-                    s_mi[3] = (M[5] * M[6] - M[3] * M[8]) * id;
-                    s_mi[4] = (M[0] * M[8] - M[2] * M[6]) * id;
-                    s_mi[5] = (M[2] * M[3] - M[0] * M[5]) * id;
-                    s_mi[6] = (M[3] * M[7] - M[4] * M[6]) * id;
-                    s_mi[7] = (M[1] * M[6] - M[0] * M[7]) * id;
-                    s_mi[8] = (M[0] * M[4] - M[1] * M[3]) * id;
+                    mi[0] = (x[4] * M8 - x[5] * x[7]) * id;
+                    mi[1] = (x[2] * x[7] - x[1] * M8) * id;
+                    mi[2] = (x[1] * x[5] - x[2] * x[4]) * id;
+                    mi[3] = (x[5] * x[6] - x[3] * M8) * id;
+                    mi[4] = (x[0] * M8 - x[2] * x[6]) * id;
+                    mi[5] = (x[2] * x[3] - x[0] * x[5]) * id;
+                    mi[6] = (x[3] * x[7] - x[4] * x[6]) * id;
+                    mi[7] = (x[1] * x[6] - x[0] * x[7]) * id;
+                    mi[8] = (x[0] * x[4] - x[1] * x[3]) * id;
                 }
             }
-            s_ok = ok ? 1 : 0;
+            if (!ok) {
+#pragma unroll
+                for (int i = 0; i < 9; i++) mi[i] = 0;
+            }
         }
         for (int i = lane; i < 256; i += 64) s_hist[i] = 0;
         __syncthreads();
 
         // warpPerspective(INTER_NEAREST, constant 0 border)
-        const bool ok = s_ok != 0;
         const int m2 = cell / 2;
         int sum = 0;
         long long sq = 0;
@@ -134,13 +162,13 @@ __global__ __launch_bounds__(64) void k_identify(const uint8_t* __restrict__ gra
             const int y = p / S, x = p - y * S;
             int v = 0;
             if (ok) {
-                const double X0 = s_mi[0] * 0 + s_mi[1] * y + s_mi[2];
-                const double Y0 = s_mi[3] * 0 + s_mi[4] * y + s_mi[5];
-                const double W0 = s_mi[6] * 0 + s_mi[7] * y + s_mi[8];
-                double Wd = W0 + s_mi[6] * x;
+                const double X0 = mi[0] * 0 + mi[1] * y + mi[2];
+                const double Y0 = mi[3] * 0 + mi[4] * y + mi[5];
+                const double W0 = mi[6] * 0 + mi[7] * y + mi[8];
+                double Wd = W0 + mi[6] * x;
                 Wd = Wd ? 1. / Wd : 0;
-                const double fX = fmax(-2147483648.0, fmin(2147483647.0, (X0 + s_mi[0] * x) * Wd));
-                const double fY = fmax(-2147483648.0, fmin(2147483647.0, (Y0 + s_mi[3] * x) * Wd));
+                const double fX = fmax(-2147483648.0, fmin(2147483647.0, (X0 + mi[0] * x) * Wd));
+                const double fY = fmax(-2147483648.0, fmin(2147483647.0, (Y0 + mi[3] * x) * Wd));
                 int X = (int)rint(fX), Y = (int)rint(fY);
                 X = min(max(X, -32768), 32767);
                 Y = min(max(Y, -32768), 32767);
