@@ -204,13 +204,13 @@ int enqueue_detect(camsync_ctx* c, const uint8_t* d_in, int B, int H, int W, int
     t.mark(1);
     launch_trace(cfg, b, c->stream);
     t.mark(2);
-    launch_quad_fit(cfg, b, c->stream);
+    launch_quad_fit(cfg, b, B, c->stream);
     t.mark(3);
     launch_identify(cfg, b, B, c->stream);
     t.mark(4);
     launch_select(cfg, b, B, c->stream);
     t.mark(5);
-    launch_subpix(cfg, b, c->stream);
+    launch_subpix(cfg, b, B, c->stream);
     t.mark(6);
     c->lastB = B;
     c->lastH = H;

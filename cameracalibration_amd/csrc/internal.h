@@ -139,10 +139,10 @@ struct DetBuffers {
 void launch_gray_thresh(const DetCfg& c, const DetBuffers& b, int B, int C, hipStream_t st);
 void launch_contour_starts(const DetCfg& c, const DetBuffers& b, int B, hipStream_t st);
 void launch_trace(const DetCfg& c, const DetBuffers& b, hipStream_t st);
-void launch_quad_fit(const DetCfg& c, const DetBuffers& b, hipStream_t st);
+void launch_quad_fit(const DetCfg& c, const DetBuffers& b, int B, hipStream_t st);
 void launch_identify(const DetCfg& c, const DetBuffers& b, int B, hipStream_t st);
 void launch_select(const DetCfg& c, const DetBuffers& b, int B, hipStream_t st);
-void launch_subpix(const DetCfg& c, const DetBuffers& b, hipStream_t st);
+void launch_subpix(const DetCfg& c, const DetBuffers& b, int B, hipStream_t st);
 
 // pose
 struct PnpArgs {

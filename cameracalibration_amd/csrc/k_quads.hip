@@ -11,6 +11,8 @@
 // before the clean-up pass can never end with 4, so it is dropped early.
 #include "internal.h"
 
+#include <algorithm>
+
 namespace camsync {
 
 namespace {
@@ -221,8 +223,11 @@ __global__ __launch_bounds__(64) void k_quad_fit(const ContourRec* __restrict__ 
 
 }  // namespace
 
-void launch_quad_fit(const DetCfg& c, const DetBuffers& b, hipStream_t st) {
-    hipLaunchKernelGGL(k_quad_fit, dim3(256 * 16), dim3(64), 0, st, b.contours, b.contourCap, b.pool, b.quads, b.qcount,
+void launch_quad_fit(const DetCfg& c, const DetBuffers& b, int B, hipStream_t st) {
+    // one wave per contour, a few hundred contours per frame; far more blocks than fit at once keeps the CUs
+    // evenly loaded (contours differ a lot in length)
+    const unsigned blocks = (unsigned)std::min(std::max(B * 128, 256), 256 * 128);
+    hipLaunchKernelGGL(k_quad_fit, dim3(blocks), dim3(64), 0, st, b.contours, b.contourCap, b.pool, b.quads, b.qcount,
                        b.counters, c);
 }
 

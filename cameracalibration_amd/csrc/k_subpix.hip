@@ -11,6 +11,8 @@
 // weights are those of the CPU path bit for bit.
 #include "internal.h"
 
+#include <algorithm>
+
 namespace camsync {
 
 namespace {
@@ -177,9 +179,11 @@ __global__ __launch_bounds__(64) void k_subpix(const uint8_t* __restrict__ gray,
 
 }  // namespace
 
-void launch_subpix(const DetCfg& c, const DetBuffers& b, hipStream_t st) {
+void launch_subpix(const DetCfg& c, const DetBuffers& b, int B, hipStream_t st) {
     if (!c.subpix) return;
-    hipLaunchKernelGGL(k_subpix, dim3(256 * 8), dim3(64), 0, st, b.gray, b.markers, b.markerCap, b.counters,
+    // one wave per corner (24 per frame in the benchmark scene)
+    const unsigned blocks = (unsigned)std::min(std::max(B * 32, 64), 256 * 128);
+    hipLaunchKernelGGL(k_subpix, dim3(blocks), dim3(64), 0, st, b.gray, b.markers, b.markerCap, b.counters,
                        b.rawCorners, b.outCorners, b.expTab, c);
 }
 
