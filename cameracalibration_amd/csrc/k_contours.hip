@@ -972,7 +972,7 @@ __global__ __launch_bounds__(64) void k_trace_store(const uint32_t* __restrict__
 void launch_contour_starts(const DetCfg& c, const DetBuffers& b, int B, hipStream_t st) {
     const unsigned long long units = (unsigned long long)B * c.nScales * plane_hb(c.H) * ((c.WS + 1) / 2);
     const unsigned long long want = (units + 63) / 64;  // at least ~16 rounds per wave (4 waves per block)
-    const unsigned blocks = (unsigned)(want < 1 ? 1 : (want < (unsigned long long)(256 * 8) ? want : (unsigned long long)(256 * 8)));
+    const unsigned blocks = (unsigned)(want < 1 ? 1 : (want < (unsigned long long)(256 * 32) ? want : (unsigned long long)(256 * 32)));
     hipLaunchKernelGGL(k_contour_starts, dim3(blocks), dim3(256), 0, st, b.planes, c, B, b.cand, b.candCap, b.counters);
 }
 
