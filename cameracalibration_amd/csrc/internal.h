@@ -85,7 +85,7 @@ struct StoreTask {
     uint32_t dst;
     uint32_t count;
 };
-constexpr int kTraceWaves = 256 * 10;  // persistent single-wave workgroups of the long-border kernels
+constexpr int kTraceWaves = 256 * 16;  // persistent single-wave workgroups of the long-border kernels
 constexpr int kCkStride = 256;         // a checkpoint (and a store task) every this many points
 constexpr int kCkMax = 32;             // checkpoints per direction: covers borders up to 2 * 32 * 256 points
 

@@ -421,23 +421,32 @@ __device__ __forceinline__ unsigned int reserve_tasks(unsigned int n, unsigned i
 // A step then costs three LDS reads instead of dependent trips to L2/HBM, and the global traffic is whole
 // 64-byte pieces that are fully used.  When any lane of the wave is about to leave its window every lane
 // close to its edge re-centres, which keeps the wave convergent.  Lanes that finish fetch new work from a queue.
+// The window is 2 x 2 pieces of 32 columns x kPieceRows rows (a piece = kPieceRows consecutive words of a
+// plane block), addressed toroidally: 64 columns x 2 kPieceRows rows, 2 kPieceRows x 8 bytes of LDS per lane.
+constexpr int kPL = 3;                       // log2(rows per piece): 8-row pieces, 8 KiB of LDS per wavefront
+constexpr int kPieceRows = 1 << kPL;
+constexpr int kWinRows = 2 * kPieceRows;
+constexpr int kTileWords = kWinRows * 2 * 64;  // LDS words per wavefront
+
 struct TileWin {
-    int gx, gy;  // window origin in half-block units: columns [32 gx, 32 gx + 64), rows [16 gy, 16 gy + 32)
+    int gx, gy;  // window origin in pieces: columns [32 gx, 32 gx + 64), rows [gy << kPL, (gy + 2) << kPL)
     bool valid;
 
     // the 3x3 neighbourhood of (x, y) lies inside the window
     __device__ __forceinline__ bool covers(int x, int y) const {
-        return valid && (unsigned)(x - (gx << 5) - 1) < 62u && (unsigned)(y - (gy << 4) - 1) < 30u;
+        return valid && (unsigned)(x - (gx << 5) - 1) < 62u && (unsigned)(y - (gy << kPL) - 1) < (unsigned)(kWinRows - 2);
     }
-    // closer than 12 columns / 6 rows to leaving the window (never true right after recentre())
+    // close to leaving the window (never true right after recentre(), which leaves >= 16 columns and
+    // kPieceRows / 2 rows of margin)
     __device__ __forceinline__ bool near_edge(int x, int y) const {
-        return !(valid && (unsigned)(x - (gx << 5) - 12) < 40u && (unsigned)(y - (gy << 4) - 6) < 20u);
+        constexpr int my = kPieceRows / 2 - 1;  // row margin that triggers a move along with the others
+        return !(valid && (unsigned)(x - (gx << 5) - 12) < 40u && (unsigned)(y - (gy << kPL) - my) < (unsigned)(kWinRows - 2 * my));
     }
     // tile word index: (row * 64 + lane) * 2 + column, i.e. one 64-bit read fetches both words of a row
     __device__ __forceinline__ void recentre(const uint32_t* __restrict__ plane, int WS, int H, int x, int y,
                                              uint32_t* __restrict__ tile, int lane) {
-        const int ngx = (x - 16) >> 5, ngy = (y - 8) >> 4;
-        const int hbRows = plane_hb(H) * 2;
+        const int ngx = (x - 16) >> 5, ngy = (y - kPieceRows / 2) >> kPL;
+        const int pieceRows = plane_hb(H) << (5 - kPL);  // pieces per plane column
 #pragma unroll
         for (int j = 0; j < 2; j++) {
 #pragma unroll
@@ -445,17 +454,23 @@ struct TileWin {
                 const int hx = ngx + i, hy = ngy + j;
                 const bool have = valid && hx >= gx && hx <= gx + 1 && hy >= gy && hy <= gy + 1;
                 if (have) continue;
-                uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0, v2 = v0, v3 = v0;
-                if (hx >= 0 && hx < WS && hy >= 0 && hy < hbRows) {
-                    const uint4* src =
-                        reinterpret_cast<const uint4*>(plane + ((size_t)(hy >> 1) * WS + hx) * 32 + (hy & 1) * 16);
-                    v0 = src[0]; v1 = src[1]; v2 = src[2]; v3 = src[3];
+                uint4 v[kPieceRows / 4];
+#pragma unroll
+                for (int q = 0; q < kPieceRows / 4; q++) v[q] = make_uint4(0, 0, 0, 0);
+                if (hx >= 0 && hx < WS && hy >= 0 && hy < pieceRows) {
+                    const uint4* src = reinterpret_cast<const uint4*>(
+                        plane + ((size_t)(hy >> (5 - kPL)) * WS + hx) * 32 + (hy & ((32 >> kPL) - 1)) * kPieceRows);
+#pragma unroll
+                    for (int q = 0; q < kPieceRows / 4; q++) v[q] = src[q];
                 }
-                uint32_t* dst = tile + ((hy & 1) * 16) * 128 + lane * 2 + (hx & 1);  // row stride 128 words
-                dst[0 * 128] = v0.x; dst[1 * 128] = v0.y; dst[2 * 128] = v0.z; dst[3 * 128] = v0.w;
-                dst[4 * 128] = v1.x; dst[5 * 128] = v1.y; dst[6 * 128] = v1.z; dst[7 * 128] = v1.w;
-                dst[8 * 128] = v2.x; dst[9 * 128] = v2.y; dst[10 * 128] = v2.z; dst[11 * 128] = v2.w;
-                dst[12 * 128] = v3.x; dst[13 * 128] = v3.y; dst[14 * 128] = v3.z; dst[15 * 128] = v3.w;
+                uint32_t* dst = tile + ((hy & 1) * kPieceRows) * 128 + lane * 2 + (hx & 1);  // row stride 128 words
+#pragma unroll
+                for (int q = 0; q < kPieceRows / 4; q++) {
+                    dst[(4 * q + 0) * 128] = v[q].x;
+                    dst[(4 * q + 1) * 128] = v[q].y;
+                    dst[(4 * q + 2) * 128] = v[q].z;
+                    dst[(4 * q + 3) * 128] = v[q].w;
+                }
             }
         }
         gx = ngx;
@@ -466,7 +481,8 @@ struct TileWin {
         const uint2* t2 = reinterpret_cast<const uint2*>(tile) + lane;
         const int xm = x - 1;
         const bool swap = (xm >> 5) & 1;
-        const uint2 r0 = t2[((y - 1) & 31) * 64], r1 = t2[(y & 31) * 64], r2 = t2[((y + 1) & 31) * 64];
+        const uint2 r0 = t2[((y - 1) & (kWinRows - 1)) * 64], r1 = t2[(y & (kWinRows - 1)) * 64],
+                    r2 = t2[((y + 1) & (kWinRows - 1)) * 64];
         // funnel shift of (next word : this word) by xm & 31 brings pixel x-1 to bit 0
         const uint32_t t = __funnelshift_r(swap ? r0.y : r0.x, swap ? r0.x : r0.y, xm) & 7u;
         const uint32_t m = __funnelshift_r(swap ? r1.y : r1.x, swap ? r1.x : r1.y, xm) & 7u;
@@ -728,7 +744,7 @@ __global__ __launch_bounds__(64) void k_trace_decide(const uint32_t* __restrict_
                                                      ContourRec* __restrict__ contours, unsigned int contourCap,
                                                      unsigned int poolCap, StoreTask* __restrict__ tasks, unsigned int taskCap,
                                                      uint32_t* __restrict__ ckpt, Counters* __restrict__ ctr) {
-    __shared__ __align__(8) uint32_t tile[32 * 2 * 64];
+    __shared__ __align__(8) uint32_t tile[kTileWords];
     const int lane = threadIdx.x;
     const bool bw = lane & 1;
     const unsigned int n = min(ctr->nLong, candCap);
@@ -905,7 +921,7 @@ __global__ __launch_bounds__(64) void k_trace_decide(const uint32_t* __restrict_
 __global__ __launch_bounds__(64) void k_trace_store(const uint32_t* __restrict__ planes, DetCfg cfg,
                                                     const StoreTask* __restrict__ tasks, unsigned int taskCap,
                                                     uint32_t* __restrict__ pool, Counters* __restrict__ ctr) {
-    __shared__ __align__(8) uint32_t tile[32 * 2 * 64];
+    __shared__ __align__(8) uint32_t tile[kTileWords];
     const int lane = threadIdx.x;
     const unsigned int n = min(ctr->nTasks, taskCap);
     const int H = cfg.H, WS = cfg.WS;
