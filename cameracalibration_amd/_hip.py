@@ -206,7 +206,7 @@ class Context:
         self._check(self._lib.camsync_gray_threshold(self._h, _ptr(f), 0, B, H, W, Cn, _ptr(gray), _ptr(binp)))
         return gray, binp
 
-    def detect(self, frames, max_markers: int = 64, max_rejected: int = 256):
+    def detect(self, frames, max_markers: int = 64, max_rejected: int = 1024):
         """Returns (ids [B,M], corners [B,M,4,2], counts [B], rejected [B,R,4,2], rej_counts [B])."""
         f = self._frames(frames)
         B, H, W, Cn = f.shape
@@ -225,7 +225,7 @@ class Context:
         return dict(candidates=int(out[0]), contours=int(out[1]), points=int(out[2]), markers=int(out[3]),
                     overflow=int(out[4]), quads=int(out[5]), long_candidates=int(out[6]), queue_head=int(out[7]))
 
-    def debug_quads(self, frame=0, cap=256):
+    def debug_quads(self, frame=0, cap=1024):
         c = np.zeros((cap, 4, 2), np.float32)
         sc, key, ln, idv, rot = (np.zeros(cap, np.int32) for _ in range(5))
         n = self._lib.camsync_debug_quads(self._h, frame, cap, _ptr(c), _ptr(sc), _ptr(key), _ptr(ln), _ptr(idv), _ptr(rot))

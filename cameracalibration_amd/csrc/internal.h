@@ -8,8 +8,8 @@
 namespace camsync {
 
 constexpr int kMaxScales = 8;
-constexpr int kQuadCap = 256;      // quad candidates kept per frame
-constexpr int kSelCap = 256;       // selected candidates per frame
+constexpr int kQuadCap = 1024;     // quad candidates kept per frame (40 markers x 3 scales x border pairs fit)
+constexpr int kSelCap = 1024;      // selected candidates per frame
 constexpr int kMaxMarkerOut = 64;  // accepted markers per frame held on device
 constexpr int kMaxRejectedOut = kSelCap;
 constexpr int kMaxAnchors = 64;

@@ -71,8 +71,9 @@ __device__ bool marker_in_marker(const float* m1, const float* m2) {
            point_in_quad(m2, m1[4], m1[5]) > 0 && point_in_quad(m2, m1[6], m1[7]) > 0;
 }
 
-constexpr int NQ = kQuadCap;
-
+// NQ: capacity of the LDS working set.  Two instances run over every frame: the small one takes the frames with
+// up to 256 candidates (nearly all of them, at a quarter of the LDS), the large one the rest.
+template <int NQ>
 __global__ __launch_bounds__(64) void k_select(const QuadRec* __restrict__ quads, const int* __restrict__ qcount,
                                                DetCfg cfg, int32_t* __restrict__ outIds, float* __restrict__ outCorners, float* __restrict__ rawCorners,
                                                int32_t* __restrict__ outCounts, float* __restrict__ outRejected,
@@ -93,8 +94,9 @@ __global__ __launch_bounds__(64) void k_select(const QuadRec* __restrict__ quads
 
     const int lane = threadIdx.x;
     const int f = blockIdx.x;
-    const int n = min(qcount[f], NQ);
-    const QuadRec* __restrict__ Q = quads + (size_t)f * NQ;
+    const int n = min(qcount[f], kQuadCap);
+    if ((n > 256) != (NQ > 256)) return;  // the other instance's frame
+    const QuadRec* __restrict__ Q = quads + (size_t)f * kQuadCap;
 
     if (n == 0) {
         if (lane == 0) { outCounts[f] = 0; outRejCounts[f] = 0; }
@@ -307,7 +309,9 @@ __global__ __launch_bounds__(64) void k_select(const QuadRec* __restrict__ quads
 }  // namespace
 
 void launch_select(const DetCfg& c, const DetBuffers& b, int B, hipStream_t st) {
-    hipLaunchKernelGGL(k_select, dim3(B), dim3(64), 0, st, b.quads, b.qcount, c, b.outIds, b.outCorners, b.rawCorners, b.outCounts,
+    hipLaunchKernelGGL(k_select<256>, dim3(B), dim3(64), 0, st, b.quads, b.qcount, c, b.outIds, b.outCorners, b.rawCorners, b.outCounts,
+                       b.outRejected, b.outRejCounts, b.markers, b.markerCap, b.counters);
+    hipLaunchKernelGGL(k_select<kQuadCap>, dim3(B), dim3(64), 0, st, b.quads, b.qcount, c, b.outIds, b.outCorners, b.rawCorners, b.outCounts,
                        b.outRejected, b.outRejCounts, b.markers, b.markerCap, b.counters);
 }
 

@@ -1,0 +1,143 @@
+"""Edge cases and the full-size configurations of BASELINE.json, through the C ABI (ctypes binding):
+empty and degenerate frames, smallest and odd frame sizes, 4K frames with 40 markers (configs[2]),
+batches that mix contents, capacity and argument errors."""
+import numpy as np
+import pytest
+
+from cameracalibration_amd import _hip, synth
+from tests import _data, _oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _same_as_oracle(ctx, frames):
+    ids, corners, counts, rej, rejc = ctx.detect(frames)
+    for b in range(len(frames)):
+        oi, oc, orj = orc.detect(frames[b])
+        n = int(counts[b])
+        assert ids[b, :n].tolist() == oi.tolist()
+        if n:
+            assert np.abs(corners[b, :n] - oc).max() <= 1e-3
+        assert int(rejc[b]) == len(orj)
+        if len(orj):
+            assert np.array_equal(rej[b, :len(orj)], orj)  # rejected quads are integer corners, same order
+    return counts
+
+
+def test_empty_and_flat_frames():
+    ctx = _hip.Context(96, 128, 4)
+    ramp = np.tile(np.arange(128, dtype=np.uint8)[None, :, None] * 2, (96, 1, 3))
+    frames = np.stack([np.zeros((96, 128, 3), np.uint8), np.full((96, 128, 3), 255, np.uint8),
+                       np.full((96, 128, 3), 128, np.uint8), ramp])
+    counts = _same_as_oracle(ctx, frames)
+    assert counts.tolist() == [0, 0, 0, 0]
+
+
+def test_white_noise_small_frame_matches_oracle():
+    """Pure white noise: thousands of contours and hundreds of quad candidates in a 96x128 frame."""
+    ctx = _hip.Context(96, 128, 1)
+    noise = np.random.default_rng(0).integers(0, 256, (1, 96, 128, 3), dtype=np.uint8)
+    _same_as_oracle(ctx, noise)
+
+
+def test_capacity_overflow_is_loud():
+    """A large frame of white noise yields more than 1024 quad candidates: the fixed per-frame list overflows and
+    the call fails with CAMSYNC_E_CAPACITY instead of dropping candidates silently."""
+    ctx = _hip.Context(480, 640, 1)
+    noise = np.random.default_rng(0).integers(0, 256, (480, 640, 3), dtype=np.uint8)
+    with pytest.raises(_hip.CamsyncError) as e:
+        ctx.detect(noise)
+    assert e.value.code == _hip.E_CAPACITY
+    ctx.detect(np.zeros((480, 640, 3), np.uint8))  # the context stays usable
+
+
+@pytest.mark.parametrize("hw", [(32, 32), (33, 40), (47, 104), (240, 320), (481, 648)])
+def test_small_and_odd_sizes(hw):
+    """Smallest supported frame, heights that are not multiples of 32, widths that are multiples of 8 only."""
+    h, w = hw
+    rng = np.random.default_rng(h * 1000 + w)
+    # a blocky random image has plenty of contours and quads at every size
+    small = rng.integers(0, 2, ((h + 7) // 8, (w + 7) // 8), dtype=np.uint8) * 200 + 20
+    img = np.kron(small, np.ones((8, 8), np.uint8))[:h, :w]
+    img = np.clip(img.astype(np.int32) + rng.integers(-6, 7, img.shape), 0, 255).astype(np.uint8)
+    ctx = _hip.Context(max(h, 32), max(w, 32), 2)
+    _same_as_oracle(ctx, np.stack([img, img[::-1].copy()])[..., None])
+
+
+def test_mixed_batch_and_context_reuse():
+    """One context, calls of different sizes and batch sizes back to back (stale scratch must not leak)."""
+    K, _ = _data.calibration("Logitec_robot_1920-1080_10.npz")
+    ctx = _hip.Context(1080, 1920, 3)
+    big = np.stack([synth.v1_frame(i, K, ss=2)[0].numpy() for i in range(3)])
+    c1 = _same_as_oracle(ctx, big)
+    assert (c1 >= 5).all()
+    pic = _data.load_bgr("pic_2.png")
+    _same_as_oracle(ctx, pic[None])
+    _same_as_oracle(ctx, big[:1])
+    # a batch larger than max_batch is processed in chunks
+    ids5, _, counts5, _, _ = ctx.detect(np.concatenate([big, big[:2]]))
+    assert counts5.tolist() == c1.tolist() + c1[:2].tolist()
+
+
+def test_4k_forty_markers_config():
+    """BASELINE configs[2]: 3840x2160, 40 markers per frame; every rendered id is found and the result equals
+    the oracle's (ids and order exactly, corners to 1e-3 px)."""
+    K = np.array([[2800.0, 0, 1920.0], [0, 2800.0, 1080.0], [0, 0, 1.0]])
+    (img, sheet, R, t) = synth.grid_frame(0, K, ss=2)
+    frame = img.numpy()
+    ctx = _hip.Context(2160, 3840, 1)
+    ids, corners, counts, _, _ = ctx.detect(frame)
+    n = int(counts[0])
+    oi, oc, _ = orc.detect(frame)
+    assert ids[0, :n].tolist() == oi.tolist() and np.abs(corners[0, :n] - oc).max() <= 1e-3
+    # the scene is rendered by this repository's own renderer: markers partly outside the frame or smaller than
+    # the minimum perimeter are legitimately missed, nothing that is not on the sheet may be reported
+    want = {int(m[0]) for m in sheet}
+    assert n >= 24 and set(ids[0, :n].tolist()) <= want
+
+
+def test_argument_errors_and_limits():
+    ctx = _hip.Context(64, 64, 1)
+    with pytest.raises(_hip.CamsyncError):
+        ctx.detect(np.zeros((128, 128, 3), np.uint8))       # larger than the context
+    with pytest.raises(_hip.CamsyncError):
+        ctx.detect(np.zeros((64, 60, 3), np.uint8))         # width not a multiple of 8
+    with pytest.raises(_hip.CamsyncError):
+        _hip.Context(16, 16, 1)                             # below the minimum size
+    p = ctx.get_params()
+    p.maxMarkerPerimeterRate = 400.0                        # would need contours of 25600 points
+    ctx.set_params(p)
+    with pytest.raises(_hip.CamsyncError):
+        ctx.detect(np.zeros((64, 64, 3), np.uint8))
+    p.maxMarkerPerimeterRate = 4.0
+    ctx.set_params(p)
+    ctx.detect(np.zeros((64, 64, 3), np.uint8))
+    # PnP: fewer than 4 points is not solvable, non-coplanar points are reported as unsupported (status 2)
+    K = np.array([[500.0, 0, 32], [0, 500.0, 32], [0, 0, 1]])
+    obj = np.zeros((1, 8, 3), np.float32); img = np.zeros((1, 8, 2), np.float32)
+    _, _, ok, _, _ = ctx.pnp(obj, img, [3], K, np.zeros(5))
+    assert ok[0] == 0
+    obj[0] = np.random.default_rng(1).normal(size=(8, 3)); obj[0, :, 2] += 5
+    img[0] = (obj[0, :, :2] / obj[0, :, 2:3]) * 500 + 32
+    _, _, ok, _, _ = ctx.pnp(obj, img, [8], K, np.zeros(5))
+    assert ok[0] == 2
+
+
+def test_generic_threshold_windows_match_oracle():
+    """Detector parameters other than the reference's take the generic (untuned) threshold kernels."""
+    ctx = _hip.Context(240, 320, 1)
+    p = ctx.get_params()
+    p.adaptiveThreshWinSizeMin, p.adaptiveThreshWinSizeMax, p.adaptiveThreshWinSizeStep = 5, 21, 8
+    p.adaptiveThreshConstant = 5.0
+    ctx.set_params(p)
+    K, _ = _data.calibration("Logitec_robot_1920-1080_10.npz")
+    frame = synth.v1_frame(1, K, ss=2)[0].numpy()[300:540, 600:920].copy()
+    op = orc.default_params()
+    op.adaptiveThreshWinSizeMin, op.adaptiveThreshWinSizeMax, op.adaptiveThreshWinSizeStep = 5, 21, 8
+    op.adaptiveThreshConstant = 5.0
+    ids, corners, counts, _, _ = ctx.detect(frame)
+    oi, oc, _ = orc.detect(frame, params=op)
+    n = int(counts[0])
+    assert ids[0, :n].tolist() == oi.tolist()
+    if n:
+        assert np.abs(corners[0, :n] - oc).max() <= 1e-3
