@@ -160,12 +160,16 @@ def main():
     n_ok = int(d_ok.to(torch.int64).sum().item())
     mean_markers = float(d_cnt.to(torch.float64).mean().item())
 
-    # per-kernel time for the roofline: one more (untimed) pass with the ctx's hipEvent stage timers
+    # per-kernel time for the roofline: three more passes with the ctx's hipEvent stage timers (events on the
+    # ctx's own stream, recorded around every stage), averaged
     ctx.enable_timers(True)
     ctx.reset_timers()
-    step()
+    n_timed = 3
+    for _ in range(n_timed):
+        step()
     tm = ctx.timers()
     ctx.enable_timers(False)
+    tm = {k: (v[0] / n_timed, v[1] // n_timed) for k, v in tm.items()}  # per step
     ms0, n0 = tm["gray_threshold"]
     px_per_launch = min(args.chunk, B) * H * W
     # launches can be short at the tail; use totals: bytes of all launches / total time
