@@ -88,7 +88,8 @@ def main():
     ap.add_argument("--chunk", type=int, default=4096, help="frames per kernel launch sequence")
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--cpu-sample", type=int, default=48)
+    ap.add_argument("--cpu-sample", type=int, default=1536,
+                    help="frames of the same workload timed on the CPU oracle (about 10 s on 16 threads)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--calib-views", type=int, default=2000)
     args = ap.parse_args()
