@@ -337,7 +337,8 @@ int camsync_create(camsync_ctx** out, int device, int max_h, int max_w, int max_
     b.bin = nullptr;
     c->planeScales = 3;
     HIPCHK(c, dalloc(&b.planes, B * c->planeScales * plane_words(max_h, (max_w + 31) / 32)));
-    b.candCap = (unsigned)std::min<size_t>(std::max<size_t>(B * (px / 32), 1u << 16), 0x7FFFFFFFu);
+    // (at least 2 MiB: after the short pass the start list holds the decide pass's tail records)
+    b.candCap = (unsigned)std::min<size_t>(std::max<size_t>(B * (px / 32), (size_t)kTraceWaves * kTailPairs * 8), 0x7FFFFFFFu);
     HIPCHK(c, dalloc(&b.cand, b.candCap));
     HIPCHK(c, dalloc(&b.candLong, b.candCap));
     // (+ the blocks the persistent border-follower waves reserve and may leave partly unused)

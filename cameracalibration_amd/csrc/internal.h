@@ -87,6 +87,7 @@ struct StoreTask {
 };
 constexpr int kTraceWaves = 256 * 16;  // persistent single-wave workgroups of the long-border kernels
 constexpr int kCkStride = 256;         // a checkpoint (and a store task) every this many points
+constexpr int kTailPairs = 8;           // a decide wave with at most this many borders left hands them to the tail pass
 constexpr int kCkMax = 32;             // checkpoints per direction: covers borders up to 2 * 32 * 256 points
 
 struct Counters {
@@ -100,7 +101,8 @@ struct Counters {
     unsigned int qStore;
     unsigned int nTasks;    // store tasks appended by the decide passes
     unsigned int qShort;    // work-queue head of the short-border kernel
-    unsigned int pad[2];
+    unsigned int nTail;     // border pairs handed from the decide pass to its tail pass
+    unsigned int pad;
 };
 
 struct DetBuffers {

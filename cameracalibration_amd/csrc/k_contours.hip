@@ -477,6 +477,45 @@ struct TileWin {
         gy = ngy;
         valid = true;
     }
+    // The same move with all the loads issued before the first LDS write: one memory latency per move instead
+    // of one per piece.  (The decide pass uses this one; in the store pass, whose loads queue behind its point
+    // stores anyway, the extra registers cost more than the overlap gains.)
+    __device__ __forceinline__ void recentre_grouped(const uint32_t* __restrict__ plane, int WS, int H, int x, int y,
+                                                     uint32_t* __restrict__ tile, int lane) {
+        const int ngx = (x - 16) >> 5, ngy = (y - kPieceRows / 2) >> kPL;
+        const int pieceRows = plane_hb(H) << (5 - kPL);
+        uint4 v[4][kPieceRows / 4];
+        bool fresh[4];
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const int hx = ngx + (p & 1), hy = ngy + (p >> 1);
+            fresh[p] = !(valid && hx >= gx && hx <= gx + 1 && hy >= gy && hy <= gy + 1);
+#pragma unroll
+            for (int q = 0; q < kPieceRows / 4; q++) v[p][q] = make_uint4(0, 0, 0, 0);
+            if (fresh[p] && hx >= 0 && hx < WS && hy >= 0 && hy < pieceRows) {
+                const uint4* src = reinterpret_cast<const uint4*>(
+                    plane + ((size_t)(hy >> (5 - kPL)) * WS + hx) * 32 + (hy & ((32 >> kPL) - 1)) * kPieceRows);
+#pragma unroll
+                for (int q = 0; q < kPieceRows / 4; q++) v[p][q] = src[q];
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            if (!fresh[p]) continue;
+            const int hx = ngx + (p & 1), hy = ngy + (p >> 1);
+            uint32_t* dst = tile + ((hy & 1) * kPieceRows) * 128 + lane * 2 + (hx & 1);
+#pragma unroll
+            for (int q = 0; q < kPieceRows / 4; q++) {
+                dst[(4 * q + 0) * 128] = v[p][q].x;
+                dst[(4 * q + 1) * 128] = v[p][q].y;
+                dst[(4 * q + 2) * 128] = v[p][q].z;
+                dst[(4 * q + 3) * 128] = v[p][q].w;
+            }
+        }
+        gx = ngx;
+        gy = ngy;
+        valid = true;
+    }
     __device__ __forceinline__ uint32_t mask(const uint32_t* __restrict__ tile, int lane, int x, int y) const {
         const uint2* t2 = reinterpret_cast<const uint2*>(tile) + lane;
         const int xm = x - 1;
@@ -737,20 +776,35 @@ __global__ __launch_bounds__(256) void k_trace_short(const uint32_t* __restrict_
     mark_empty_tasks(tasks, taskA.cur, taskA.end, lane);
 }
 
+// A border in flight, as one lane of its pair holds it (the tail pass resumes from these).
+struct TailRec {
+    uint64_t c;
+    uint32_t count, pos, prevState, state0, ck, pad;
+};
+static_assert(sizeof(TailRec) == 32, "tail records are sized against the start list");
+
 // Decide the long candidates (canonical start? length within bounds?), reserve pool space and cut the accepted
 // borders into store tasks.  Lanes 2p (forward) and 2p + 1 (backward) work on the same candidate.
+//
+// The lengths are heavy-tailed: once the queue is empty most waves would spend two thirds of their life
+// following one or two very long borders with 60 idle lanes, all of them competing for issue slots.  A wave
+// whose queue is empty and that has at most kTailPairs borders left therefore writes their state to the tail
+// list and exits; the RESUME instance packs those borders 32 to a wave and finishes them.
+template <bool RESUME>
 __global__ __launch_bounds__(64) void k_trace_decide(const uint32_t* __restrict__ planes, DetCfg cfg,
                                                      const uint64_t* __restrict__ candLong, unsigned int candCap,
+                                                     TailRec* __restrict__ tail,
                                                      ContourRec* __restrict__ contours, unsigned int contourCap,
                                                      unsigned int poolCap, StoreTask* __restrict__ tasks, unsigned int taskCap,
                                                      uint32_t* __restrict__ ckpt, Counters* __restrict__ ctr) {
     __shared__ __align__(8) uint32_t tile[kTileWords];
     const int lane = threadIdx.x;
     const bool bw = lane & 1;
-    const unsigned int n = min(ctr->nLong, candCap);
+    const unsigned int n = RESUME ? 0u : min(ctr->nLong, candCap);
     const int H = cfg.H, W = cfg.W, WS = cfg.WS, S = cfg.nScales;
     const size_t perPlane = plane_words(H, WS);
-    uint32_t* const myCk = ckpt + (((size_t)blockIdx.x * 32 + (lane >> 1)) * 2 + (bw ? 1 : 0)) * kCkMax;
+    uint32_t ckSlot = ((uint32_t)blockIdx.x * 32 + (lane >> 1)) * 2 + (bw ? 1 : 0);
+    uint32_t* myCk = ckpt + (size_t)ckSlot * kCkMax;
 
     bool active = false, exhausted = false, fresh = false, isHole = false;
     uint64_t c = 0;
@@ -763,7 +817,53 @@ __global__ __launch_bounds__(64) void k_trace_decide(const uint32_t* __restrict_
     WaveQueue queue;
     WaveAlloc poolA, slotA, taskA;
 
+    if (RESUME) {
+        // one record per lane, pairs adjacent; nothing else to fetch
+        const unsigned int nRec = 2u * min(ctr->nTail, (unsigned int)(kTraceWaves * kTailPairs));
+        const unsigned int i = blockIdx.x * 64u + (unsigned int)lane;
+        if (i < nRec) {
+            const TailRec r = tail[i];
+            c = r.c;
+            const uint32_t pos = (uint32_t)(c & 0xFFFFFFFFull);
+            plane = planes + ((size_t)(uint32_t)(c >> 40) * S + (int)((c >> 36) & 7u)) * perPlane;
+            isHole = (c >> 39) & 1u;
+            startKey = (int)pos;
+            count = (int)r.count;
+            cx = (int)(r.pos & 0xFFFu);
+            cy = (int)((r.pos >> 12) & 0xFFFu);
+            s = (int)(r.pos >> 24);
+            prevState = r.prevState;
+            state0 = r.state0;
+            ckSlot = r.ck;
+            myCk = ckpt + (size_t)ckSlot * kCkMax;
+            active = true;
+        }
+        exhausted = true;
+    }
+
     for (;;) {
+        // ---- a wave left with a few borders and an empty queue hands them to the tail pass ----
+        if (!RESUME && queue.empty()) {
+            const unsigned long long am = __ballot(active);
+            const int np = __popcll(am) >> 1;
+            if (np > 0 && np <= kTailPairs) {
+                unsigned int base = 0;
+                if (lane == 0) base = atomicAdd(&ctr->nTail, (unsigned int)np);
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (active) {
+                    TailRec r;
+                    r.c = c;
+                    r.count = (uint32_t)count;
+                    r.pos = pack_state(cx, cy, s);
+                    r.prevState = prevState;
+                    r.state0 = state0;
+                    r.ck = ckSlot;
+                    r.pad = 0;
+                    tail[2u * base + (unsigned int)__popcll(am & ((1ull << lane) - 1ull))] = r;
+                }
+                break;
+            }
+        }
         // ---- idle pairs fetch their next candidate (the queue hands out every index below n exactly once) ----
         {
             const bool need = !active && !exhausted;
@@ -793,7 +893,7 @@ __global__ __launch_bounds__(64) void k_trace_decide(const uint32_t* __restrict_
 
         // ---- keep every active lane's window around its pixel ----
         if (__any(active && !win.covers(cx, cy))) {
-            if (active && win.near_edge(cx, cy)) win.recentre(plane, WS, H, cx, cy, tile, lane);
+            if (active && win.near_edge(cx, cy)) win.recentre_grouped(plane, WS, H, cx, cy, tile, lane);
         }
 
         // res: -1 keep going, 0 drop, > 0 the border closed with that many points
@@ -928,8 +1028,8 @@ __global__ __launch_bounds__(64) void k_trace_store(const uint32_t* __restrict__
     const size_t perPlane = plane_words(H, WS);
 
     bool active = false, exhausted = false;
-    int left = 0, cx = 1, cy = 1, s = 0;
-    uint32_t* out = nullptr;
+    int left = 0, cx = 1, cy = 1, s = 0, nq = 0;
+    uint32_t oidx = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0;  // pool index of the next point; points not yet written
     const uint32_t* plane = planes;
     TileWin win;
     win.gx = win.gy = 0;
@@ -948,7 +1048,8 @@ __global__ __launch_bounds__(64) void k_trace_store(const uint32_t* __restrict__
                     cy = (int)((k.state >> 12) & 0xFFFu);
                     s = (int)(k.state >> 24);
                     left = (int)k.count;
-                    out = pool + k.dst;
+                    oidx = k.dst;
+                    nq = 0;
                     win.valid = false;
                     active = left > 0;
                 } else if (queue.empty()) {
@@ -969,8 +1070,28 @@ __global__ __launch_bounds__(64) void k_trace_store(const uint32_t* __restrict__
                 const int s0 = fresh_dir(m, s == 9);
                 s = s0 < 0 ? 0 : s0;  // a single pixel has count 1 and stops below before s is used
             }
-            *out++ = (uint32_t)cx | ((uint32_t)cy << 16);
-            if (--left == 0) {
+            // the last four points wait in registers: a 16-byte store per aligned group of four instead of four
+            // scattered 4-byte stores (the head and the tail of a task are written point by point)
+            q0 = q1;
+            q1 = q2;
+            q2 = q3;
+            q3 = (uint32_t)cx | ((uint32_t)cy << 16);
+            nq++;
+            --left;
+            if ((oidx & 3u) == 3u || left == 0) {
+                if (nq >= 4 && (oidx & 3u) == 3u) {
+                    *reinterpret_cast<uint4*>(pool + (oidx - 3u)) = make_uint4(q0, q1, q2, q3);
+                } else {
+                    const int m = nq < 4 ? nq : 4;  // only a task's first or last group gets here
+                    pool[oidx] = q3;
+                    if (m > 1) pool[oidx - 1u] = q2;
+                    if (m > 2) pool[oidx - 2u] = q1;
+                    if (m > 3) pool[oidx - 3u] = q0;
+                }
+                nq = 0;
+            }
+            oidx++;
+            if (left == 0) {
                 active = false;
             } else {
                 const uint32_t rot = ((m >> (s + 1)) | (m << (7 - s))) & 0xFFu;
@@ -996,8 +1117,12 @@ void launch_trace(const DetCfg& c, const DetBuffers& b, hipStream_t st) {
     hipLaunchKernelGGL(k_trace_short, dim3(256 * 8), dim3(256), 0, st, b.planes, c, b.cand, b.candCap, b.candLong,
                        b.contours, b.contourCap, b.poolCap, b.tasks, b.taskCap, b.counters);
     // persistent: 10 single-wave workgroups per CU (16 KiB of LDS each)
-    hipLaunchKernelGGL(k_trace_decide, dim3(kTraceWaves), dim3(64), 0, st, b.planes, c, b.candLong, b.candCap, b.contours,
-                       b.contourCap, b.poolCap, b.tasks, b.taskCap, b.ckpt, b.counters);
+    // (the start list is free after the short pass: it holds the tail records)
+    TailRec* tail = reinterpret_cast<TailRec*>(b.cand);
+    hipLaunchKernelGGL(k_trace_decide<false>, dim3(kTraceWaves), dim3(64), 0, st, b.planes, c, b.candLong, b.candCap, tail,
+                       b.contours, b.contourCap, b.poolCap, b.tasks, b.taskCap, b.ckpt, b.counters);
+    hipLaunchKernelGGL(k_trace_decide<true>, dim3(kTraceWaves * kTailPairs / 32), dim3(64), 0, st, b.planes, c, b.candLong,
+                       b.candCap, tail, b.contours, b.contourCap, b.poolCap, b.tasks, b.taskCap, b.ckpt, b.counters);
     hipLaunchKernelGGL(k_trace_store, dim3(kTraceWaves), dim3(64), 0, st, b.planes, c, b.tasks, b.taskCap, b.pool, b.counters);
 }
 

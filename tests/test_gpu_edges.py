@@ -41,12 +41,16 @@ def test_white_noise_small_frame_matches_oracle():
 
 
 def test_capacity_overflow_is_loud():
-    """A large frame of white noise yields more than 1024 quad candidates: the fixed per-frame list overflows and
-    the call fails with CAMSYNC_E_CAPACITY instead of dropping candidates silently."""
+    """1200 small dark squares give more than 1024 quad candidates in one frame (each is found at several threshold
+    scales): the fixed per-frame list overflows and the call fails with CAMSYNC_E_CAPACITY instead of dropping
+    candidates silently."""
     ctx = _hip.Context(480, 640, 1)
-    noise = np.random.default_rng(0).integers(0, 256, (480, 640, 3), dtype=np.uint8)
+    img = np.full((480, 640), 220, np.uint8)
+    for r in range(30):
+        for c in range(40):
+            img[r * 16 + 3:r * 16 + 13, c * 16 + 3:c * 16 + 13] = 30
     with pytest.raises(_hip.CamsyncError) as e:
-        ctx.detect(noise)
+        ctx.detect(img[..., None])
     assert e.value.code == _hip.E_CAPACITY
     ctx.detect(np.zeros((480, 640, 3), np.uint8))  # the context stays usable
 
