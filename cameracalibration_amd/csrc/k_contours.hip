@@ -442,45 +442,10 @@ struct TileWin {
         constexpr int my = kPieceRows / 2 - 1;  // row margin that triggers a move along with the others
         return !(valid && (unsigned)(x - (gx << 5) - 12) < 40u && (unsigned)(y - (gy << kPL) - my) < (unsigned)(kWinRows - 2 * my));
     }
-    // tile word index: (row * 64 + lane) * 2 + column, i.e. one 64-bit read fetches both words of a row
+    // tile word index: (row * 64 + lane) * 2 + column, i.e. one 64-bit read fetches both words of a row.
+    // All the loads of a move are issued before the first LDS write: one memory latency per move instead of one
+    // per piece.
     __device__ __forceinline__ void recentre(const uint32_t* __restrict__ plane, int WS, int H, int x, int y,
-                                             uint32_t* __restrict__ tile, int lane) {
-        const int ngx = (x - 16) >> 5, ngy = (y - kPieceRows / 2) >> kPL;
-        const int pieceRows = plane_hb(H) << (5 - kPL);  // pieces per plane column
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-#pragma unroll
-            for (int i = 0; i < 2; i++) {
-                const int hx = ngx + i, hy = ngy + j;
-                const bool have = valid && hx >= gx && hx <= gx + 1 && hy >= gy && hy <= gy + 1;
-                if (have) continue;
-                uint4 v[kPieceRows / 4];
-#pragma unroll
-                for (int q = 0; q < kPieceRows / 4; q++) v[q] = make_uint4(0, 0, 0, 0);
-                if (hx >= 0 && hx < WS && hy >= 0 && hy < pieceRows) {
-                    const uint4* src = reinterpret_cast<const uint4*>(
-                        plane + ((size_t)(hy >> (5 - kPL)) * WS + hx) * 32 + (hy & ((32 >> kPL) - 1)) * kPieceRows);
-#pragma unroll
-                    for (int q = 0; q < kPieceRows / 4; q++) v[q] = src[q];
-                }
-                uint32_t* dst = tile + ((hy & 1) * kPieceRows) * 128 + lane * 2 + (hx & 1);  // row stride 128 words
-#pragma unroll
-                for (int q = 0; q < kPieceRows / 4; q++) {
-                    dst[(4 * q + 0) * 128] = v[q].x;
-                    dst[(4 * q + 1) * 128] = v[q].y;
-                    dst[(4 * q + 2) * 128] = v[q].z;
-                    dst[(4 * q + 3) * 128] = v[q].w;
-                }
-            }
-        }
-        gx = ngx;
-        gy = ngy;
-        valid = true;
-    }
-    // The same move with all the loads issued before the first LDS write: one memory latency per move instead
-    // of one per piece.  (The decide pass uses this one; in the store pass, whose loads queue behind its point
-    // stores anyway, the extra registers cost more than the overlap gains.)
-    __device__ __forceinline__ void recentre_grouped(const uint32_t* __restrict__ plane, int WS, int H, int x, int y,
                                                      uint32_t* __restrict__ tile, int lane) {
         const int ngx = (x - 16) >> 5, ngy = (y - kPieceRows / 2) >> kPL;
         const int pieceRows = plane_hb(H) << (5 - kPL);
@@ -893,7 +858,7 @@ __global__ __launch_bounds__(64) void k_trace_decide(const uint32_t* __restrict_
 
         // ---- keep every active lane's window around its pixel ----
         if (__any(active && !win.covers(cx, cy))) {
-            if (active && win.near_edge(cx, cy)) win.recentre_grouped(plane, WS, H, cx, cy, tile, lane);
+            if (active && win.near_edge(cx, cy)) win.recentre(plane, WS, H, cx, cy, tile, lane);
         }
 
         // res: -1 keep going, 0 drop, > 0 the border closed with that many points
@@ -1029,7 +994,7 @@ __global__ __launch_bounds__(64) void k_trace_store(const uint32_t* __restrict__
 
     bool active = false, exhausted = false;
     int left = 0, cx = 1, cy = 1, s = 0, nq = 0;
-    uint32_t oidx = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0;  // pool index of the next point; points not yet written
+    uint32_t oidx = 0, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // pool index of the next point; points not yet written
     const uint32_t* plane = planes;
     TileWin win;
     win.gx = win.gy = 0;
@@ -1070,23 +1035,23 @@ __global__ __launch_bounds__(64) void k_trace_store(const uint32_t* __restrict__
                 const int s0 = fresh_dir(m, s == 9);
                 s = s0 < 0 ? 0 : s0;  // a single pixel has count 1 and stops below before s is used
             }
-            // the last four points wait in registers: a 16-byte store per aligned group of four instead of four
-            // scattered 4-byte stores (the head and the tail of a task are written point by point)
-            q0 = q1;
-            q1 = q2;
-            q2 = q3;
-            q3 = (uint32_t)cx | ((uint32_t)cy << 16);
+            // the last eight points wait in registers: two 16-byte stores per aligned group of eight instead of
+            // eight scattered 4-byte stores (the head and the tail of a task are written point by point)
+#pragma unroll
+            for (int k = 0; k < 7; k++) q[k] = q[k + 1];
+            q[7] = (uint32_t)cx | ((uint32_t)cy << 16);
             nq++;
             --left;
-            if ((oidx & 3u) == 3u || left == 0) {
-                if (nq >= 4 && (oidx & 3u) == 3u) {
-                    *reinterpret_cast<uint4*>(pool + (oidx - 3u)) = make_uint4(q0, q1, q2, q3);
+            if ((oidx & 7u) == 7u || left == 0) {
+                if (nq >= 8 && (oidx & 7u) == 7u) {
+                    uint4* dst = reinterpret_cast<uint4*>(pool + (oidx - 7u));
+                    dst[0] = make_uint4(q[0], q[1], q[2], q[3]);
+                    dst[1] = make_uint4(q[4], q[5], q[6], q[7]);
                 } else {
-                    const int m = nq < 4 ? nq : 4;  // only a task's first or last group gets here
-                    pool[oidx] = q3;
-                    if (m > 1) pool[oidx - 1u] = q2;
-                    if (m > 2) pool[oidx - 2u] = q1;
-                    if (m > 3) pool[oidx - 3u] = q0;
+                    const int m = nq < 8 ? nq : 8;  // only a task's first or last group gets here
+#pragma unroll
+                    for (int k = 0; k < 8; k++)
+                        if (m > k) pool[oidx - (uint32_t)k] = q[7 - k];
                 }
                 nq = 0;
             }
