@@ -755,6 +755,7 @@ static_assert(sizeof(TailRec) == 32, "tail records are sized against the start l
 // following one or two very long borders with 60 idle lanes, all of them competing for issue slots.  A wave
 // whose queue is empty and that has at most kTailPairs borders left therefore writes their state to the tail
 // list and exits; the RESUME instance packs those borders 32 to a wave and finishes them.
+constexpr int kTailLanes = 64;  // borders (x2) per wave of the tail pass: few, so that window moves are rare
 template <bool RESUME>
 __global__ __launch_bounds__(64) void k_trace_decide(const uint32_t* __restrict__ planes, DetCfg cfg,
                                                      const uint64_t* __restrict__ candLong, unsigned int candCap,
@@ -785,8 +786,8 @@ __global__ __launch_bounds__(64) void k_trace_decide(const uint32_t* __restrict_
     if (RESUME) {
         // one record per lane, pairs adjacent; nothing else to fetch
         const unsigned int nRec = 2u * min(ctr->nTail, (unsigned int)(kTraceWaves * kTailPairs));
-        const unsigned int i = blockIdx.x * 64u + (unsigned int)lane;
-        if (i < nRec) {
+        const unsigned int i = blockIdx.x * (unsigned int)kTailLanes + (unsigned int)lane;
+        if (lane < kTailLanes && i < nRec) {
             const TailRec r = tail[i];
             c = r.c;
             const uint32_t pos = (uint32_t)(c & 0xFFFFFFFFull);
@@ -861,65 +862,64 @@ __global__ __launch_bounds__(64) void k_trace_decide(const uint32_t* __restrict_
             if (active && win.near_edge(cx, cy)) win.recentre(plane, WS, H, cx, cy, tile, lane);
         }
 
-        // res: -1 keep going, 0 drop, > 0 the border closed with that many points
-        int res = -1;
-        uint32_t newState = 0;
-        bool abort = false;
-        if (active) {
-            const uint32_t m = win.mask(tile, lane, cx, cy);
-            if (fresh) {
-                // both lanes start from the start state (P0, s0); the backward lane first steps to P0 + s0
+        // ---- new pairs take their start state (P0, s0); the backward lane first steps to P0 + s0 (uniform branch:
+        //      rare, and the step below follows in the same round) ----
+        if (__any(active && fresh)) {
+            if (active && fresh) {
+                const uint32_t m = win.mask(tile, lane, cx, cy);
                 fresh = false;
                 const int s0 = fresh_dir(m, isHole);  // never -1 here: single pixels end in the short pass
                 s = s0 < 0 ? 0 : s0;
                 state0 = prevState = pack_state(cx, cy, s);
-                if (bw) {
+                if (bw) {  // (the window keeps a margin after a move, one pixel further is still covered)
                     cx += fast_dx(s);
                     cy += fast_dy(s);
                     s ^= 4;  // now: direction towards the pixel we came from, the forward successor
                 }
-                newState = state0;
-            } else {
-                // One step, forward (T) or backward (T^-1), on one code path (the two lanes of a pair would
-                // otherwise serialise two branches every iteration).
-                //   forward : from (P, s) sweep counter-clockwise from s + 1 to the first foreground neighbour d;
-                //             the pixel counted is P, the new state is (P + d, d + 4).
-                //   backward: at pixel P whose forward successor lies in direction s, the predecessor p is the
-                //             first foreground neighbour clockwise from s - 1; bit-reversing the mask turns
-                //             clockwise into increasing bit numbers.  The state completed is (P, p).
-                const uint32_t mm = bw ? (__brev(m) >> 24) : m;      // backward: bit b <-> direction 7 - b
-                const int b0 = bw ? ((8 - s) & 7) : ((s + 1) & 7);    // first bit looked at
-                const uint32_t rot = ((mm >> b0) | (mm << (8 - b0))) & 0xFFu;
-                const int j = __ffs(rot) - 1;                          // zeros swept (m always holds a neighbour)
-                const int q = bw ? ((s - 1 - j) & 7) : ((s + 1 + j) & 7);  // direction found: p or d
-                // the sweep passed the east neighbour: forward s + 1 + j >= 9, backward 1 <= s <= j
-                const bool east = bw ? (s >= 1 && s <= j) : (s + j >= 8);
-                if ((!isHole || east) && cy * W + cx < startKey) abort = true;  // smaller key: not canonical
-                const uint32_t here = pack_state(cx, cy, bw ? q : s);  // forward: A_count, backward: B_(count+1)
-                if (!bw && (count & (kCkStride - 1)) == 0 && count) myCk[min(count / kCkStride, kCkMax - 1)] = here;
-                count++;
-                if (bw && (count & (kCkStride - 1)) == 0) myCk[min(count / kCkStride, kCkMax - 1)] = here;
-                cx += fast_dx(q);
-                cy += fast_dy(q);
-                s = q ^ 4;
-                newState = bw ? here : pack_state(cx, cy, s);
             }
         }
-        // ---- the pair compares notes (both lanes of a pair are active or idle together) ----
-        const uint32_t pNew = from_partner(newState | (abort ? 0x80000000u : 0u));
-        const uint32_t pOld = from_partner(prevState);
-        if (active && count) {
+
+        // res: -1 keep going, 0 drop, > 0 the border closed with that many points
+        int res = -1;
+        if (active) {
+            // One step, forward (T) or backward (T^-1), on one branch-free code path (this chain of dependent
+            // instructions, times the length of the longest border, bounds the kernel).
+            //   forward : from (P, s) sweep counter-clockwise from s + 1 to the first foreground neighbour d;
+            //             the pixel counted is P, the new state is (P + d, d + 4).
+            //   backward: at pixel P whose forward successor lies in direction s, the predecessor p is the
+            //             first foreground neighbour clockwise from s - 1; bit-reversing the mask turns
+            //             clockwise into increasing bit numbers.  The state completed is (P, p).
+            const uint32_t m = win.mask(tile, lane, cx, cy);
+            const uint32_t mm = bw ? (__brev(m) >> 24) : m;   // backward: bit b <-> direction 7 - b
+            const int b0 = (bw ? 8 - s : s + 1) & 7;           // first bit looked at
+            const uint32_t rot = ((mm >> b0) | (mm << (8 - b0))) & 0xFFu;
+            const int j = __builtin_ctz(rot | 0x100u);         // zeros swept (m always holds a neighbour)
+            const int q = (bw ? s - 1 - j : s + 1 + j) & 7;    // direction found: p or d
+            // the sweep passed the east neighbour: forward s + 1 + j >= 9, backward 1 <= s <= j
+            const bool east = (unsigned int)(bw ? s - 1 : 7 - s) < (unsigned int)j;
+            const int key = (int)__umul24((unsigned int)cy, (unsigned int)W) + cx;
+            const bool abort = (!isHole || east) && key < startKey;  // smaller key: not the canonical start
+            const uint32_t here = pack_state(cx, cy, bw ? q : s);
+            const int hi = count + (bw ? 1 : 0);               // `here` is A_count (forward) or B_(count + 1)
+            if ((hi & (kCkStride - 1)) == 0 && hi) myCk[(hi / kCkStride) & (kCkMax - 1)] = here;
+            count++;
+            cx += fast_dx(q);
+            cy += fast_dy(q);
+            s = q ^ 4;
+            const uint32_t newState = bw ? here : pack_state(cx, cy, s);
+            // ---- the pair compares notes (both lanes of a pair are active or idle together) ----
+            const uint32_t pNew = from_partner(newState | (abort ? 0x80000000u : 0u));
+            const uint32_t pOld = from_partner(prevState);
             const bool anyAbort = abort || (pNew >> 31);
             const uint32_t pn = pNew & 0x7FFFFFFFu;
-            int total = -1;
-            if (pn == newState) total = 2 * count;                                   // met: every state counted once
-            else if (bw ? (pn == prevState) : (newState == pOld)) total = 2 * count - 1;  // crossed: one pixel counted twice
+            const bool met = pn == newState;                                         // every state counted once
+            const bool crossed = (bw ? pn : newState) == (bw ? prevState : pOld);   // one pixel counted twice
+            const int total = 2 * count - (met ? 0 : 1);
+            res = (met || crossed) ? (total > cfg.maxPerim ? 0 : total)
+                                   : (2 * count - 1 > cfg.maxPerim ? 0 : -1);  // more points than allowed whatever follows
             if (anyAbort) res = 0;
-            else if (total > 0) res = total;
-            else if (2 * count - 1 > cfg.maxPerim) res = 0;  // more points than allowed whatever happens next
-            if (total > cfg.maxPerim) res = 0;
+            prevState = newState;
         }
-        if (active) prevState = bw ? newState : newState;
         // ---- accepted borders: the wave hands out space border by border (uniform loop), then the pair writes ----
         const bool accept = res >= cfg.minPerim && res <= cfg.maxPerim;
         const unsigned int nt = (unsigned int)((count + kCkStride - 1) / kCkStride);  // tasks of this lane's half
@@ -1031,9 +1031,9 @@ __global__ __launch_bounds__(64) void k_trace_store(const uint32_t* __restrict__
         }
         if (active) {
             const uint32_t m = win.mask(tile, lane, cx, cy);
-            if (s >= 8) {  // fresh start: initial search (s - 8 = hole flag)
+            if (__any(s >= 8)) {  // fresh start: initial search (s - 8 = hole flag); rare, so a uniform branch
                 const int s0 = fresh_dir(m, s == 9);
-                s = s0 < 0 ? 0 : s0;  // a single pixel has count 1 and stops below before s is used
+                if (s >= 8) s = s0 < 0 ? 0 : s0;  // a single pixel has count 1 and stops below before s is used
             }
             // the last eight points wait in registers: two 16-byte stores per aligned group of eight instead of
             // eight scattered 4-byte stores (the head and the tail of a task are written point by point)
@@ -1086,7 +1086,7 @@ void launch_trace(const DetCfg& c, const DetBuffers& b, hipStream_t st) {
     TailRec* tail = reinterpret_cast<TailRec*>(b.cand);
     hipLaunchKernelGGL(k_trace_decide<false>, dim3(kTraceWaves), dim3(64), 0, st, b.planes, c, b.candLong, b.candCap, tail,
                        b.contours, b.contourCap, b.poolCap, b.tasks, b.taskCap, b.ckpt, b.counters);
-    hipLaunchKernelGGL(k_trace_decide<true>, dim3(kTraceWaves * kTailPairs / 32), dim3(64), 0, st, b.planes, c, b.candLong,
+    hipLaunchKernelGGL(k_trace_decide<true>, dim3(kTraceWaves * kTailPairs * 2 / kTailLanes), dim3(64), 0, st, b.planes, c, b.candLong,
                        b.candCap, tail, b.contours, b.contourCap, b.poolCap, b.tasks, b.taskCap, b.ckpt, b.counters);
     hipLaunchKernelGGL(k_trace_store, dim3(kTraceWaves), dim3(64), 0, st, b.planes, c, b.tasks, b.taskCap, b.pool, b.counters);
 }
