@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void k_contour_starts(const uint32_t* __restri
     const int WP = (WS + 1) >> 1;
     const size_t perPlane = plane_words(H, WS);
     const bool dropIsolated = cfg.minPerim > 1;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     uint64_t* const stage = s_list[wv];
     unsigned int staged = 0;  // uniform
 
@@ -93,68 +93,94 @@ __global__ __launch_bounds__(256) void k_contour_starts(const uint32_t* __restri
     unsigned long long u = units * w / nw;
     const unsigned long long uEnd = units * (w + 1) / nw;
     // decode once, then count up
-    int p = (int)(u % WP);
+    // (wave-uniform values: kept in scalar registers)
     unsigned long long t = u / WP;
-    int by = (int)(t % HB);
-    unsigned int fs = (unsigned int)(t / HB);
-    // the words of a round are loaded one round ahead, so a wave always has a round's loads in flight
-    struct Words { uint32_t c, cl, cr, n, nl, nr, s, sl, sr; };
+    int p = __builtin_amdgcn_readfirstlane((int)(u % WP));
+    int by = __builtin_amdgcn_readfirstlane((int)(t % HB));
+    unsigned int fs = (unsigned int)__builtin_amdgcn_readfirstlane((int)(t / HB));
+    unsigned int left = (unsigned int)__builtin_amdgcn_readfirstlane((int)(uEnd - u));        // units of this wave
+    const unsigned int avail = (unsigned int)__builtin_amdgcn_readfirstlane((int)(units - u < 0x7FFFFFFFull ? units - u : 0x7FFFFFFFull));  // units up to the end
+    auto advance = [&](int& pp, int& bby, unsigned int& ffs) {
+        if (++pp == WP) {
+            pp = 0;
+            if (++bby == HB) {
+                bby = 0;
+                ffs++;
+            }
+        }
+    };
+    // The words of a round are loaded one round ahead, so a wave always has a round's loads in flight.  A lane
+    // loads only its own word (and lanes 0/32 and 31/63 the rows just above and below the block pair); the words
+    // of the blocks to the left and right -- of which only the adjacent bit matters -- come from the other half
+    // of the wave, from the round before (kept in registers) and from the round after (already loaded).
+    struct Words { uint32_t c, n, s; };
+    const Words kZero = {0u, 0u, 0u};
     const int r = lane & 31;
+    const bool half0 = lane < 32;
     auto load_unit = [&](int pp, int bby, unsigned int ffs) {
-        Words q = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+        Words q = kZero;
         const int bx = 2 * pp + (lane >> 5);
         const uint32_t* plane = planes + (size_t)ffs * perPlane;
         if (bx < WS) {
             const size_t ci = ((size_t)bby * WS + bx) * 32 + r;
             q.c = plane[ci];
-            if (bx > 0) q.cl = plane[ci - 32];
-            if (bx + 1 < WS) q.cr = plane[ci + 32];
-            if (r == 0 && bby > 0) {  // the row above the first row of a block lives in the block above
-                const size_t ai = ((size_t)(bby - 1) * WS + bx) * 32 + 31;
-                q.n = plane[ai];
-                if (bx > 0) q.nl = plane[ai - 32];
-                if (bx + 1 < WS) q.nr = plane[ai + 32];
-            }
-            if (r == 31 && bby + 1 < HB) {  // and the row below the last row in the block below
-                const size_t bi = ((size_t)(bby + 1) * WS + bx) * 32;
-                q.s = plane[bi];
-                if (bx > 0) q.sl = plane[bi - 32];
-                if (bx + 1 < WS) q.sr = plane[bi + 32];
-            }
+            // the row above the first row of a block lives in the block above, the row below the last in the block below
+            if (r == 0 && bby > 0) q.n = plane[((size_t)(bby - 1) * WS + bx) * 32 + 31];
+            if (r == 31 && bby + 1 < HB) q.s = plane[((size_t)(bby + 1) * WS + bx) * 32];
         }
         return q;
     };
-    Words cur = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
-    if (u < uEnd) cur = load_unit(p, by, fs);
-    for (; u < uEnd; u++) {
-        int np = p + 1, nby = by;
-        unsigned int nfs = fs;
-        if (np == WP) {
-            np = 0;
-            if (++nby == HB) {
-                nby = 0;
-                nfs++;
-            }
-        }
-        Words nxt = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
-        if (u + 1 < uEnd) nxt = load_unit(np, nby, nfs);
+    // the same words as the other half of the wave holds them (lane ^ 32)
+    auto other_half = [&](const Words& q) {
+        Words o;
+        const auto a = __builtin_amdgcn_permlane32_swap(q.c, q.c, false, false);
+        const auto b = __builtin_amdgcn_permlane32_swap(q.n, q.n, false, false);
+        const auto d = __builtin_amdgcn_permlane32_swap(q.s, q.s, false, false);
+        o.c = half0 ? a[1] : a[0];
+        o.n = half0 ? b[1] : b[0];
+        o.s = half0 ? d[1] : d[0];
+        return o;
+    };
+    auto lane_before = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false); };
+    auto lane_after = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false); };
+    // Two rounds of loads are in flight: the unit after this one is needed in this round (its left block is the
+    // right neighbour of this unit's right block), the one after that is requested now.
+    Words cur = kZero, curO = kZero, prevO = kZero, nxt = kZero;
+    int np = p, nby = by;
+    unsigned int nfs = fs;
+    advance(np, nby, nfs);
+    if (left) {
+        cur = load_unit(p, by, fs);
+        if (avail > 1) nxt = load_unit(np, nby, nfs);
+        if (p > 0) prevO = other_half(load_unit(p - 1, by, fs));
+        curO = other_half(cur);
+    }
+    for (unsigned int it = 0; it < left; it++) {
+        int np2 = np, nby2 = nby;
+        unsigned int nfs2 = nfs;
+        advance(np2, nby2, nfs2);
+        Words nxt2 = kZero;
+        if (it + 2 < avail) nxt2 = load_unit(np2, nby2, nfs2);
+        const Words nxtO = other_half(nxt);
+        const Words rightO = np != 0 ? nxtO : kZero;  // a new row of blocks starts: nothing to the right
 
         const int bx = 2 * p + (lane >> 5), y = by * 32 + r;
         const uint32_t* plane = planes + (size_t)fs * perPlane;
-        const uint32_t c = cur.c, cl = cur.cl, cr = cur.cr;
+        const uint32_t c = cur.c;
+        const uint32_t cl = half0 ? prevO.c : curO.c, cr = half0 ? curO.c : rightO.c;
         // the row above: the lane before, except for the first row of a block
-        uint32_t n = __shfl_up(c, 1, 64), nl = __shfl_up(cl, 1, 64), nr = __shfl_up(cr, 1, 64);
+        uint32_t n = lane_before(c), nl = lane_before(cl), nr = lane_before(cr);
         if (r == 0) {
             n = cur.n;
-            nl = cur.nl;
-            nr = cur.nr;
+            nl = half0 ? prevO.n : curO.n;
+            nr = half0 ? curO.n : rightO.n;
         }
         // the row below likewise (only the isolated-pixel test looks at it)
-        uint32_t sd = __shfl_down(c, 1, 64), sl = __shfl_down(cl, 1, 64), sr = __shfl_down(cr, 1, 64);
+        uint32_t sd = lane_after(c), sl = lane_after(cl), sr = lane_after(cr);
         if (r == 31) {
             sd = cur.s;
-            sl = cur.sl;
-            sr = cur.sr;
+            sl = half0 ? prevO.s : curO.s;
+            sr = half0 ? curO.s : rightO.s;
         }
         uint32_t outer = 0, hole = 0;
         if ((c | n) && y <= H - 2) {  // nothing can start in an all-zero word under an all-zero word
@@ -241,15 +267,12 @@ __global__ __launch_bounds__(256) void k_contour_starts(const uint32_t* __restri
                 staged += layer;
             }
         }
+        prevO = np != 0 ? curO : kZero;
         cur = nxt;
-        // next block pair
-        if (++p == WP) {
-            p = 0;
-            if (++by == HB) {
-                by = 0;
-                fs++;
-            }
-        }
+        curO = nxtO;
+        nxt = nxt2;
+        p = np; by = nby; fs = nfs;
+        np = np2; nby = nby2; nfs = nfs2;
     }
     flush();
 }
