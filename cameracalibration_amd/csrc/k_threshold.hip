@@ -131,7 +131,67 @@ __device__ __forceinline__ void widen8(uint2 v, uint32_t o[4]) {
     o[3] = __builtin_amdgcn_perm(0u, v.y, 0x0C030C02u);
 }
 
-// Sliding horizontal sum of radius R over the exchanged vertical sums.
+// a + / - one 16-bit half of w, and k times one byte of w: the sub-dword operand selects of the SDWA encoding
+// take the field straight out of the packed word, so the sums never have to be unpacked (that unpacking was a
+// quarter of this kernel's vector instructions).
+#define CAMSYNC_SDWA2(name, op, sel)                                                                              \
+    __device__ __forceinline__ uint32_t name(uint32_t a, uint32_t w) {                                           \
+        uint32_t d;                                                                                               \
+        asm(op " %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:" sel                  \
+            : "=v"(d) : "v"(a), "v"(w));                                                                          \
+        return d;                                                                                                 \
+    }
+CAMSYNC_SDWA2(add_lo16, "v_add_u32_sdwa", "WORD_0")
+CAMSYNC_SDWA2(add_hi16, "v_add_u32_sdwa", "WORD_1")
+CAMSYNC_SDWA2(sub_lo16, "v_sub_u32_sdwa", "WORD_0")
+CAMSYNC_SDWA2(sub_hi16, "v_sub_u32_sdwa", "WORD_1")
+#undef CAMSYNC_SDWA2
+#define CAMSYNC_MULB(name, sel)                                                                                   \
+    __device__ __forceinline__ uint32_t name(uint32_t w, uint32_t k) {                                           \
+        uint32_t d;                                                                                               \
+        asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" sel " src1_sel:DWORD" \
+            : "=v"(d) : "v"(w), "v"(k));                                                                          \
+        return d;                                                                                                 \
+    }
+CAMSYNC_MULB(mul_b0, "BYTE_0")
+CAMSYNC_MULB(mul_b1, "BYTE_1")
+CAMSYNC_MULB(mul_b2, "BYTE_2")
+CAMSYNC_MULB(mul_b3, "BYTE_3")
+#undef CAMSYNC_MULB
+
+// value t of a row of packed words (value t = half t & 1 of word t >> 1)
+template <int T>
+__device__ __forceinline__ uint32_t add16(uint32_t a, const uint32_t* w) {
+    return (T & 1) ? add_hi16(a, w[T >> 1]) : add_lo16(a, w[T >> 1]);
+}
+template <int T>
+__device__ __forceinline__ uint32_t sub16(uint32_t a, const uint32_t* w) {
+    return (T & 1) ? sub_hi16(a, w[T >> 1]) : sub_lo16(a, w[T >> 1]);
+}
+template <int LO, int R, int J>
+struct WinInit {  // a + sum of values LO - R .. LO - R + J - 1
+    static __device__ __forceinline__ uint32_t run(uint32_t a, const uint32_t* w) {
+        return add16<LO - R + J - 1>(WinInit<LO, R, J - 1>::run(a, w), w);
+    }
+};
+template <int LO, int R>
+struct WinInit<LO, R, 0> {
+    static __device__ __forceinline__ uint32_t run(uint32_t a, const uint32_t*) { return a; }
+};
+template <int LO, int R, int I>
+struct WinSlide {  // out[I] from out[I - 1]
+    static __device__ __forceinline__ void run(const uint32_t* w, uint32_t* out) {
+        WinSlide<LO, R, I - 1>::run(w, out);
+        out[I] = sub16<LO + I - 1 - R>(add16<LO + I + R>(out[I - 1], w), w);
+    }
+};
+template <int LO, int R>
+struct WinSlide<LO, R, 0> {
+    static __device__ __forceinline__ void run(const uint32_t*, uint32_t*) {}
+};
+
+// Sliding horizontal sum of radius R over the exchanged vertical sums, starting from `init` (the caller folds
+// the threshold's constant in there).
 // The exchange buffer of one scale is laid out by word: word j (two sums) of every lane is contiguous,
 // xb[j * XROW + XPAD + lane], so that whichever word offset a lane reads from its neighbours, the 64 lanes
 // of the instruction touch 64 consecutive words (no bank conflicts; a 16-byte lane stride read 4 bytes at a
@@ -139,39 +199,32 @@ __device__ __forceinline__ void widen8(uint2 v, uint32_t o[4]) {
 constexpr int XPAD = 4;             // lanes of slack on either side of a word row
 constexpr int XROW = TPB + 2 * XPAD;
 template <int R>
-__device__ __forceinline__ void hsum8(const uint32_t* xb, int lane, uint32_t out[8]) {
+__device__ __forceinline__ void hsum8(const uint32_t* xb, int lane, uint32_t init, uint32_t out[8]) {
     // window of pixel i covers values [i-R, i+R] relative to the lane's first; fetch words [-LO/2, 4+LO/2)
     constexpr int LO = (R + 1) & ~1;  // even offset >= R
     constexpr int N = 8 + 2 * LO;     // values fetched
-    uint32_t v[N];
+    uint32_t w[N / 2];
 #pragma unroll
     for (int i = 0; i < N / 2; i++) {
         const int d = i - LO / 2;  // word offset from the lane's first word: lane + (d >> 2), word d & 3
-        const uint32_t w = xb[(d & 3) * XROW + XPAD + lane + (d >> 2)];
-        v[2 * i] = w & 0xFFFFu;
-        v[2 * i + 1] = w >> 16;
+        w[i] = xb[(d & 3) * XROW + XPAD + lane + (d >> 2)];
     }
-    uint32_t s = 0;
-#pragma unroll
-    for (int j = -R; j <= R; j++) s += v[LO + j];
-    out[0] = s;
-#pragma unroll
-    for (int i = 1; i < 8; i++) {
-        s += v[LO + i + R];
-        s -= v[LO + i - 1 - R];
-        out[i] = s;
-    }
+    out[0] = WinInit<LO, R, 2 * R + 1>::run(init, w);
+    WinSlide<LO, R, 7>::run(w, out);
 }
 
-// bit i of the result = (s[i] >= K c[i] + C), built most significant first with compare + add-with-carry
-template <int K>
-__device__ __forceinline__ uint32_t thresh_bits(const uint32_t s[8], const uint32_t c[8], int cst) {
+// bit i of the result = (s[i] >= K c[i]) as signed numbers (s starts from minus the threshold's constant), built
+// most significant first with compare + add-with-carry; c = the 8 centre bytes, k = K in a register
+__device__ __forceinline__ uint32_t thresh_bits(const uint32_t s[8], uint2 c, uint32_t k) {
     uint32_t acc = 0;
-#pragma unroll
-    for (int i = 7; i >= 0; i--) {
-        const int t = (int)c[i] * K + cst;
-        acc = acc + acc + (((int)s[i] >= t) ? 1u : 0u);
-    }
+    acc = acc + acc + (((int)s[7] >= (int)mul_b3(c.y, k)) ? 1u : 0u);
+    acc = acc + acc + (((int)s[6] >= (int)mul_b2(c.y, k)) ? 1u : 0u);
+    acc = acc + acc + (((int)s[5] >= (int)mul_b1(c.y, k)) ? 1u : 0u);
+    acc = acc + acc + (((int)s[4] >= (int)mul_b0(c.y, k)) ? 1u : 0u);
+    acc = acc + acc + (((int)s[3] >= (int)mul_b3(c.x, k)) ? 1u : 0u);
+    acc = acc + acc + (((int)s[2] >= (int)mul_b2(c.x, k)) ? 1u : 0u);
+    acc = acc + acc + (((int)s[1] >= (int)mul_b1(c.x, k)) ? 1u : 0u);
+    acc = acc + acc + (((int)s[0] >= (int)mul_b0(c.x, k)) ? 1u : 0u);
     return acc;
 }
 
@@ -199,6 +252,9 @@ __global__ __launch_bounds__(TPB) void k_gray_thresh3(const uint8_t* __restrict_
     const bool inOut = (tid >= HALO / PX) && (tid < TPB - HALO / PX) && xbase < W;  // produces output
     const bool fullOut = inOut && (xbase + 7 < W) && aligned;
     constexpr int K0 = (2 * R0 + 1) * (2 * R0 + 1), K1 = (2 * R1 + 1) * (2 * R1 + 1), K2 = (2 * R2 + 1) * (2 * R2 + 1);
+    // (the window areas live in vector registers: the SDWA multiply takes no literal)
+    uint32_t kk0 = K0, kk1 = K1, kk2 = K2;
+    asm volatile("" : "+v"(kk0), "+v"(kk1), "+v"(kk2));
     const int c0 = ((2 * idelta - 1) * K0 + 1) >> 1, c1 = ((2 * idelta - 1) * K1 + 1) >> 1, c2 = ((2 * idelta - 1) * K2 + 1) >> 1;
 
     // vertical running sums, two 16-bit fields per word (at most 23 * 255 per field)
@@ -248,45 +304,48 @@ __global__ __launch_bounds__(TPB) void k_gray_thresh3(const uint8_t* __restrict_
         *reinterpret_cast<uint2*>(&ring[slot(y0 + d)][PX * tid]) = g;
         accumulate(g, d);
     }
-    // dl[k] = row y + RMAX - k at the top of iteration y (dl[0] is the row loaded in that iteration)
-    uint2 dl[RMAX + 1];
+    // The row loop is unrolled by UNR so that neither the rows in flight nor the delay line are moved between
+    // registers every row: moving the destination of a load that is still in flight waits for that load, which
+    // took the row prefetch away and left the kernel waiting for memory once per row.
+    // A[i] = gray row y + i at the top of the group that starts at row y (A[0 .. RMAX-1] valid, the rest filled
+    // by the group's rows); pend[j] = the raw row y + RMAX + j, in flight.
+    constexpr int UNR = 4;
+    uint2 A[RMAX + UNR];
 #pragma unroll
-    for (int k = RMAX; k >= 1; k--) {
-        dl[k] = load_gray8(in, C, W, rowOffOf(y0 + RMAX - k), xbase, aligned);
-        accumulate(dl[k], RMAX - k);
+    for (int k = 0; k < RMAX; k++) {
+        A[k] = load_gray8(in, C, W, rowOffOf(y0 + k), xbase, aligned);
+        accumulate(A[k], k);
     }
-
-    // rows y+RMAX .. y+RMAX+AHEAD-1 are in flight at the top of iteration y (aligned frames; otherwise the
-    // slow per-pixel loader fetches the row when it is needed)
-    constexpr int AHEAD = 3;
-    RawRow pend[AHEAD];
 #pragma unroll
-    for (int k = 0; k < AHEAD; k++) pend[k] = issue_row(in, C, W, rowOffOf(y0 + RMAX + k), aligned ? xbase : 0);
-    for (int y = y0; y < y1; y++) {
-        dl[0] = aligned ? gray_of(pend[0], C, W, xbase) : load_gray8(in, C, W, rowOffOf(y + RMAX), xbase, false);
+    for (int k = RMAX; k < RMAX + UNR; k++) A[k] = make_uint2(0, 0);
+    RawRow pend[UNR];
 #pragma unroll
-        for (int k = 0; k + 1 < AHEAD; k++) pend[k] = pend[k + 1];
-        pend[AHEAD - 1] = issue_row(in, C, W, rowOffOf(y + RMAX + AHEAD), aligned ? xbase : 0);
+    for (int k = 0; k < UNR; k++) pend[k] = issue_row(in, C, W, rowOffOf(y0 + RMAX + k), aligned ? xbase : 0);
+    for (int yg = y0; yg < y1; yg += UNR) {
+#pragma unroll
+      for (int j = 0; j < UNR; j++) {
+        const int y = yg + j;
+        if (y >= y1) break;
+        A[RMAX + j] = aligned ? gray_of(pend[j], C, W, xbase) : load_gray8(in, C, W, rowOffOf(y + RMAX), xbase, false);
+        pend[j] = issue_row(in, C, W, rowOffOf(y + RMAX + UNR), aligned ? xbase : 0);
 
         uint32_t a[4], b[4];
-        // every window takes in the row r_k below the centre (delay line) and drops the row r_k + 1 above it (ring)
-        widen8(dl[0], a);
+        // every window takes in the row r_k below the centre (registers) and drops the row r_k + 1 above it (ring)
+        widen8(A[R2 + j], a);
         widen8(*reinterpret_cast<const uint2*>(&ring[slot(y - R2 - 1)][PX * tid]), b);
 #pragma unroll
         for (int i = 0; i < 4; i++) V2[i] = V2[i] + a[i] - b[i];
-        widen8(dl[R2 - R1], a);
+        widen8(A[R1 + j], a);
         widen8(*reinterpret_cast<const uint2*>(&ring[slot(y - R1 - 1)][PX * tid]), b);
 #pragma unroll
         for (int i = 0; i < 4; i++) V1[i] = V1[i] + a[i] - b[i];
-        widen8(dl[R2 - R0], a);
+        widen8(A[R0 + j], a);
         widen8(*reinterpret_cast<const uint2*>(&ring[slot(y - R0 - 1)][PX * tid]), b);
 #pragma unroll
         for (int i = 0; i < 4; i++) V0[i] = V0[i] + a[i] - b[i];
-        const uint2 cen = dl[R2];  // row y
-        // row y replaces row y-RMAX-1 in the ring (read just above), and the delay line moves on
+        const uint2 cen = A[j];  // row y
+        // row y replaces row y-RMAX-1 in the ring (read just above)
         *reinterpret_cast<uint2*>(&ring[slot(y)][PX * tid]) = cen;
-#pragma unroll
-        for (int k = RMAX; k >= 1; k--) dl[k] = dl[k - 1];
 
         // exchange vertical sums (single wavefront: the barrier only orders this wave's LDS traffic)
         wave_lds_sync();
@@ -299,13 +358,12 @@ __global__ __launch_bounds__(TPB) void k_gray_thresh3(const uint8_t* __restrict_
         wave_lds_sync();
 
         if (inOut) {
-            uint32_t c[8], s0[8], s1[8], s2[8];
-            unpack8(cen, c);
-            hsum8<R0>(xbuf[0], tid, s0);
-            hsum8<R1>(xbuf[1], tid, s1);
-            hsum8<R2>(xbuf[2], tid, s2);
+            uint32_t s0[8], s1[8], s2[8];
+            hsum8<R0>(xbuf[0], tid, (uint32_t)-c0, s0);
+            hsum8<R1>(xbuf[1], tid, (uint32_t)-c1, s1);
+            hsum8<R2>(xbuf[2], tid, (uint32_t)-c2, s2);
             // one byte per scale, bit i = pixel xbase+i
-            const uint32_t pm0 = thresh_bits<K0>(s0, c, c0), pm1 = thresh_bits<K1>(s1, c, c1), pm2 = thresh_bits<K2>(s2, c, c2);
+            const uint32_t pm0 = thresh_bits(s0, cen, kk0), pm1 = thresh_bits(s1, cen, kk1), pm2 = thresh_bits(s2, cen, kk2);
             const size_t off = frameOff + (size_t)y * W + xbase;
             if (fullOut) {
                 if (bin) {
@@ -322,7 +380,7 @@ __global__ __launch_bounds__(TPB) void k_gray_thresh3(const uint8_t* __restrict_
                 for (int i = 0; i < 8; i++)
                     if (xbase + i < W) {
                         if (bin) bin[off + i] = (uint8_t)(((pm0 >> i) & 1u) | (((pm1 >> i) & 1u) << 1) | (((pm2 >> i) & 1u) << 2));
-                        if (gray) gray[off + i] = (uint8_t)c[i];
+                        if (gray) gray[off + i] = (uint8_t)(((i < 4 ? cen.x : cen.y) >> (8 * (i & 3))) & 255u);
                     }
             }
             // bit planes with the 1-pixel image frame zeroed (what findContours works on)
@@ -337,6 +395,9 @@ __global__ __launch_bounds__(TPB) void k_gray_thresh3(const uint8_t* __restrict_
             q[2 * NBLK * STG * 4] = (uint8_t)(pm2 & keep);
         }
         if ((y & (STG - 1)) == STG - 1) flush(y / STG);
+      }
+#pragma unroll
+      for (int k = 0; k < RMAX; k++) A[k] = A[k + UNR];
     }
     // the band that ends the image also writes the zero rows that pad the last block row
     if (y1 == H) {
