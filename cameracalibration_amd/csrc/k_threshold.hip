@@ -196,7 +196,7 @@ struct WinSlide<LO, R, 0> {
 // xb[j * XROW + XPAD + lane], so that whichever word offset a lane reads from its neighbours, the 64 lanes
 // of the instruction touch 64 consecutive words (no bank conflicts; a 16-byte lane stride read 4 bytes at a
 // time hits every bank four times, and that made this kernel LDS-bound).
-constexpr int XPAD = 4;             // lanes of slack on either side of a word row
+constexpr int XPAD = 0;             // lanes of slack on either side of a word row (producing lanes stay 2 lanes inside)
 constexpr int XROW = TPB + 2 * XPAD;
 template <int R>
 __device__ __forceinline__ void hsum8(const uint32_t* xb, int lane, uint32_t init, uint32_t out[8]) {
@@ -213,32 +213,40 @@ __device__ __forceinline__ void hsum8(const uint32_t* xb, int lane, uint32_t ini
     WinSlide<LO, R, 7>::run(w, out);
 }
 
-// bit i of the result = (s[i] >= K c[i]) as signed numbers (s starts from minus the threshold's constant), built
-// most significant first with compare + add-with-carry; c = the 8 centre bytes, k = K in a register
+// bit i of the result = (s[i] > K c[i]) as signed numbers (the caller starts s from 1 minus the threshold's
+// constant, which makes this the >= of the definition).  K c - s is negative exactly then, and a funnel shift
+// appends its sign bit to the byte under construction: multiply, subtract, shift per pixel, no condition codes
+// (a compare feeding a select costs wait states on this chip).  c = the 8 centre bytes, k = K in a register.
 __device__ __forceinline__ uint32_t thresh_bits(const uint32_t s[8], uint2 c, uint32_t k) {
     uint32_t acc = 0;
-    acc = acc + acc + (((int)s[7] >= (int)mul_b3(c.y, k)) ? 1u : 0u);
-    acc = acc + acc + (((int)s[6] >= (int)mul_b2(c.y, k)) ? 1u : 0u);
-    acc = acc + acc + (((int)s[5] >= (int)mul_b1(c.y, k)) ? 1u : 0u);
-    acc = acc + acc + (((int)s[4] >= (int)mul_b0(c.y, k)) ? 1u : 0u);
-    acc = acc + acc + (((int)s[3] >= (int)mul_b3(c.x, k)) ? 1u : 0u);
-    acc = acc + acc + (((int)s[2] >= (int)mul_b2(c.x, k)) ? 1u : 0u);
-    acc = acc + acc + (((int)s[1] >= (int)mul_b1(c.x, k)) ? 1u : 0u);
-    acc = acc + acc + (((int)s[0] >= (int)mul_b0(c.x, k)) ? 1u : 0u);
+    acc = __builtin_amdgcn_alignbit(acc, mul_b3(c.y, k) - s[7], 31);
+    acc = __builtin_amdgcn_alignbit(acc, mul_b2(c.y, k) - s[6], 31);
+    acc = __builtin_amdgcn_alignbit(acc, mul_b1(c.y, k) - s[5], 31);
+    acc = __builtin_amdgcn_alignbit(acc, mul_b0(c.y, k) - s[4], 31);
+    acc = __builtin_amdgcn_alignbit(acc, mul_b3(c.x, k) - s[3], 31);
+    acc = __builtin_amdgcn_alignbit(acc, mul_b2(c.x, k) - s[2], 31);
+    acc = __builtin_amdgcn_alignbit(acc, mul_b1(c.x, k) - s[1], 31);
+    acc = __builtin_amdgcn_alignbit(acc, mul_b0(c.x, k) - s[0], 31);
     return acc;
 }
 
-template <int R0, int R1, int R2>
-__global__ __launch_bounds__(TPB) void k_gray_thresh3(const uint8_t* __restrict__ in, int C, uint8_t* __restrict__ gray,
-                                                      uint8_t* __restrict__ bin, uint32_t* __restrict__ planes, int WS, int H, int W, int bandH, int idelta) {
+// MODE 1 / 2: the common cases compiled with their parameters fixed (3 / 1 input channels, width a multiple of
+// 8, no packed threshold image asked for), so that the row loop is straight-line code whose loads the compiler
+// can track across rows; MODE 0 takes them at run time.
+template <int R0, int R1, int R2, int MODE>
+__global__ __launch_bounds__(TPB) void k_gray_thresh3(const uint8_t* __restrict__ in, int C_, uint8_t* __restrict__ gray,
+                                                      uint8_t* __restrict__ bin_, uint32_t* __restrict__ planes, int WS, int H, int W, int bandH, int idelta) {
+    const int C = MODE == 1 ? 3 : MODE == 2 ? 1 : C_;
+    uint8_t* const bin = MODE ? nullptr : bin_;
+    const bool hasGray = MODE ? true : gray != nullptr;
     constexpr int RMAX = R2;
     constexpr int RING = RMAX + 1;  // rows y-1 .. y-rmax-1; rows y .. y+rmax sit in the register delay line
     static_assert(R0 <= R1 && R1 <= R2 && R2 <= HALO - 1, "radii must be sorted and fit the halo");
     __shared__ __align__(16) uint8_t ring[RING][ROWPX];
     __shared__ uint32_t xbuf[3][4 * XROW];  // vertical sums of one row, by word (hsum8)
-    // 16 rows of plane bits of this strip, laid out like the planes (scale, block, row): flushed as 64-byte pieces
+    // STG rows of plane bits of this strip, laid out like the planes (scale, block, row): flushed as 16-byte pieces
     constexpr int NBLK = CHUNKW / 32;
-    constexpr int STG = 8;  // rows staged per flush
+    constexpr int STG = 8;  // rows staged per flush (four: flushing costs more than the sixteenth wave per CU gains)
     __shared__ __align__(16) uint32_t stage[3][NBLK][STG];
 
     const int tid = threadIdx.x;
@@ -247,7 +255,7 @@ __global__ __launch_bounds__(TPB) void k_gray_thresh3(const uint8_t* __restrict_
     const int y1 = min(H, y0 + bandH);
     const int cx0 = blockIdx.x * CHUNKW;
     const int xbase = cx0 - HALO + PX * tid;
-    const bool aligned = (W % 8) == 0;
+    const bool aligned = MODE ? true : (W % 8) == 0;
     const size_t frameOff = (size_t)f * H * W;
     const bool inOut = (tid >= HALO / PX) && (tid < TPB - HALO / PX) && xbase < W;  // produces output
     const bool fullOut = inOut && (xbase + 7 < W) && aligned;
@@ -359,9 +367,9 @@ __global__ __launch_bounds__(TPB) void k_gray_thresh3(const uint8_t* __restrict_
 
         if (inOut) {
             uint32_t s0[8], s1[8], s2[8];
-            hsum8<R0>(xbuf[0], tid, (uint32_t)-c0, s0);
-            hsum8<R1>(xbuf[1], tid, (uint32_t)-c1, s1);
-            hsum8<R2>(xbuf[2], tid, (uint32_t)-c2, s2);
+            hsum8<R0>(xbuf[0], tid, (uint32_t)(1 - c0), s0);
+            hsum8<R1>(xbuf[1], tid, (uint32_t)(1 - c1), s1);
+            hsum8<R2>(xbuf[2], tid, (uint32_t)(1 - c2), s2);
             // one byte per scale, bit i = pixel xbase+i
             const uint32_t pm0 = thresh_bits(s0, cen, kk0), pm1 = thresh_bits(s1, cen, kk1), pm2 = thresh_bits(s2, cen, kk2);
             const size_t off = frameOff + (size_t)y * W + xbase;
@@ -375,12 +383,12 @@ __global__ __launch_bounds__(TPB) void k_gray_thresh3(const uint8_t* __restrict_
                     o.y = ob[4] | (ob[5] << 8) | (ob[6] << 16) | (ob[7] << 24);
                     *reinterpret_cast<uint2*>(bin + off) = o;
                 }
-                if (gray) *reinterpret_cast<uint2*>(gray + off) = cen;
+                if (hasGray) *reinterpret_cast<uint2*>(gray + off) = cen;
             } else {
                 for (int i = 0; i < 8; i++)
                     if (xbase + i < W) {
                         if (bin) bin[off + i] = (uint8_t)(((pm0 >> i) & 1u) | (((pm1 >> i) & 1u) << 1) | (((pm2 >> i) & 1u) << 2));
-                        if (gray) gray[off + i] = (uint8_t)(((i < 4 ? cen.x : cen.y) >> (8 * (i & 3))) & 255u);
+                        if (hasGray) gray[off + i] = (uint8_t)(((i < 4 ? cen.x : cen.y) >> (8 * (i & 3))) & 255u);
                     }
             }
             // bit planes with the 1-pixel image frame zeroed (what findContours works on)
@@ -473,14 +481,33 @@ void launch_gray_thresh(const DetCfg& c, const DetBuffers& b, int B, int C, hipS
     const bool fast = c.nScales == 3 && c.radius[0] == 1 && c.radius[1] == 6 && c.radius[2] == 11;
     if (fast) {
         const int chunks = (c.W + CHUNKW - 1) / CHUNKW;
-        // single-wave workgroups: enough of them to fill 256 CUs (10 waves each) a few times over, bands no
-        // shorter than 64 rows (every band re-reads 2*rmax+1 rows above it to warm its running sums up)
-        int bands = (8192 + B * chunks - 1) / (B * chunks);
-        bands = max(1, min(bands, (c.H + 63) / 64));
-        int bandH = (((c.H + bands - 1) / bands) + 31) & ~31;  // whole plane blocks per band
-        bands = (c.H + bandH - 1) / bandH;
+        // Single-wave workgroups of equal length, 15 resident per CU (LDS): the launch runs in rounds, and a last
+        // round that is mostly empty costs as much as a full one.  Choose the number of bands per strip that
+        // minimises rounds x band length; every band re-reads 2 rmax + 2 rows above it to warm its running sums
+        // up (about 12 rows' worth of time), and bands are whole plane blocks.
+        const long slots = 256L * 15;
+        const int maxBands = max(1, (c.H + 63) / 64);
+        int bands = 1, bandH = (c.H + 31) & ~31;
+        long best = -1;
+        for (int nb = 1; nb <= maxBands; nb++) {
+            const int bh = (((c.H + nb - 1) / nb) + 31) & ~31;
+            const int real = (c.H + bh - 1) / bh;
+            const long rounds = ((long)B * chunks * real + slots - 1) / slots;
+            const long cost = rounds * (bh + 12);
+            if (best < 0 || cost < best) {
+                best = cost;
+                bands = real;
+                bandH = bh;
+            }
+        }
         dim3 grid(chunks, bands, B);
-        hipLaunchKernelGGL((k_gray_thresh3<1, 6, 11>), grid, dim3(TPB), 0, st, b.in, C, b.gray, b.bin, b.planes, c.WS, c.H, c.W, bandH, c.idelta);
+        const bool plain = (c.W % 8) == 0 && !b.bin && b.gray;
+        if (plain && C == 3)
+            hipLaunchKernelGGL((k_gray_thresh3<1, 6, 11, 1>), grid, dim3(TPB), 0, st, b.in, C, b.gray, b.bin, b.planes, c.WS, c.H, c.W, bandH, c.idelta);
+        else if (plain && C == 1)
+            hipLaunchKernelGGL((k_gray_thresh3<1, 6, 11, 2>), grid, dim3(TPB), 0, st, b.in, C, b.gray, b.bin, b.planes, c.WS, c.H, c.W, bandH, c.idelta);
+        else
+            hipLaunchKernelGGL((k_gray_thresh3<1, 6, 11, 0>), grid, dim3(TPB), 0, st, b.in, C, b.gray, b.bin, b.planes, c.WS, c.H, c.W, bandH, c.idelta);
     } else {
         size_t total = (size_t)B * c.H * c.W;
         unsigned blocks = (unsigned)((total + 255) / 256);
