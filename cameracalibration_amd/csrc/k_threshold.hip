@@ -21,6 +21,8 @@
 // (k^2 is odd, so the rounded mean never ties and the last division is exact).
 #include "internal.h"
 
+#include <type_traits>
+
 namespace camsync {
 
 namespace {
@@ -276,9 +278,13 @@ __global__ __launch_bounds__(TPB) void k_gray_thresh3(const uint8_t* __restrict_
     auto flush = [&](int g) {
         wave_lds_sync();
         constexpr int Q = STG / 4;  // 16-byte pieces per block and scale
-        for (int i = tid; i < 3 * NBLK * Q; i += TPB) {
+        // (straight-line: a loop with stores in it makes the compiler wait for every load in flight at the top
+        // of the row loop)
+#pragma unroll
+        for (int it = 0; it < (3 * NBLK * Q + TPB - 1) / TPB; it++) {
+            const int i = tid + it * TPB;
             const int sc = i / (NBLK * Q), rem = i - sc * (NBLK * Q), blk = rem / Q, q = rem % Q;
-            if (bx0 + blk < WS) {
+            if (i < 3 * NBLK * Q && bx0 + blk < WS) {
                 const uint4 v = *reinterpret_cast<const uint4*>(&stage[sc][blk][q * 4]);
                 const int row0 = g * STG;  // first row of the group
                 uint32_t* dst = fplanes + (size_t)sc * perPlane + ((size_t)(row0 >> 5) * WS + bx0 + blk) * 32 + (row0 & 31) + q * 4;
@@ -329,11 +335,9 @@ __global__ __launch_bounds__(TPB) void k_gray_thresh3(const uint8_t* __restrict_
     RawRow pend[UNR];
 #pragma unroll
     for (int k = 0; k < UNR; k++) pend[k] = issue_row(in, C, W, rowOffOf(y0 + RMAX + k), aligned ? xbase : 0);
-    for (int yg = y0; yg < y1; yg += UNR) {
-#pragma unroll
-      for (int j = 0; j < UNR; j++) {
-        const int y = yg + j;
-        if (y >= y1) break;
+    // one row; j = its place in the group (a compile-time constant, so that A and pend are registers)
+    auto do_row = [&](const int y, auto jc) {
+        constexpr int j = decltype(jc)::value;
         A[RMAX + j] = aligned ? gray_of(pend[j], C, W, xbase) : load_gray8(in, C, W, rowOffOf(y + RMAX), xbase, false);
         pend[j] = issue_row(in, C, W, rowOffOf(y + RMAX + UNR), aligned ? xbase : 0);
 
@@ -403,10 +407,22 @@ __global__ __launch_bounds__(TPB) void k_gray_thresh3(const uint8_t* __restrict_
             q[2 * NBLK * STG * 4] = (uint8_t)(pm2 & keep);
         }
         if ((y & (STG - 1)) == STG - 1) flush(y / STG);
-      }
+    };
+    // whole groups without an early exit (an exit between the rows of a group makes the compiler assume that
+    // the loads of the first row are the youngest in flight, and wait for all of them at the top of the loop)
+    int yg = y0;
+    for (; yg + UNR <= y1; yg += UNR) {
+        do_row(yg, std::integral_constant<int, 0>());
+        do_row(yg + 1, std::integral_constant<int, 1>());
+        do_row(yg + 2, std::integral_constant<int, 2>());
+        do_row(yg + 3, std::integral_constant<int, 3>());
 #pragma unroll
-      for (int k = 0; k < RMAX; k++) A[k] = A[k + UNR];
+        for (int k = 0; k < RMAX; k++) A[k] = A[k + UNR];
     }
+    static_assert(UNR == 4, "the row groups are written out for four rows");
+    if (yg < y1) do_row(yg, std::integral_constant<int, 0>());
+    if (yg + 1 < y1) do_row(yg + 1, std::integral_constant<int, 1>());
+    if (yg + 2 < y1) do_row(yg + 2, std::integral_constant<int, 2>());
     // the band that ends the image also writes the zero rows that pad the last block row
     if (y1 == H) {
         for (int yy = H; yy < plane_hb(H) * 32; yy++) {
