@@ -724,7 +724,7 @@ __global__ __launch_bounds__(256) void k_trace_short(const uint32_t* __restrict_
         while (am) {
             const int l = __ffsll((long long)am) - 1;
             am &= am - 1;
-            const unsigned int len = (unsigned int)__shfl(res, l, 64);
+            const unsigned int len = (unsigned int)__builtin_amdgcn_readlane(res, l);
             uint2 left;
             const unsigned int off = poolA.take(len, kShortPoolBlock, &ctr->nPool, poolCap, 4u, ctr, lane, left);
             const unsigned int slot = slotA.take(1, kSlotBlock, &ctr->nContours, contourCap, 2u, ctr, lane, left);
@@ -951,7 +951,7 @@ __global__ __launch_bounds__(64) void k_trace_decide(const uint32_t* __restrict_
         while (am) {
             const int l = __ffsll((long long)am) - 1;
             am &= am - 1;
-            const unsigned int len = (unsigned int)__shfl(res, l, 64), ntl = __shfl(nt, l, 64);
+            const unsigned int len = (unsigned int)__builtin_amdgcn_readlane(res, l), ntl = (unsigned int)__builtin_amdgcn_readlane((int)nt, l);
             uint2 left;
             const unsigned int off = poolA.take(len, kPoolBlock, &ctr->nPool, poolCap, 4u, ctr, lane, left);
             const unsigned int slot = slotA.take(1, kSlotBlock, &ctr->nContours, contourCap, 2u, ctr, lane, left);

@@ -10,6 +10,7 @@
 // the samples, build the histogram in LDS and vote the cells; the dictionary
 // is searched one entry per lane.
 #include "internal.h"
+#include "wave_reduce.h"
 
 namespace camsync {
 
@@ -25,14 +26,10 @@ __device__ __forceinline__ double lane_get(double v, int src) {
 }
 
 __device__ __forceinline__ int wave_sum_i(int v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-    return v;
+    return wave_allreduce(v, [](int a, int b) { return a + b; });
 }
 __device__ __forceinline__ long long wave_sum_ll(long long v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-    return v;
+    return wave_allreduce(v, [](long long a, long long b) { return a + b; });
 }
 
 // Code of a markerSize x markerSize bit grid (given as a row-major MSB-first
@@ -313,7 +310,7 @@ __global__ __launch_bounds__(64) void k_identify(const uint8_t* __restrict__ gra
                     if (hit) {
                         const int src = __ffsll((long long)hit) - 1;
                         id = m0 + src;
-                        rot = __shfl(bestRot, src, 64);
+                        rot = __builtin_amdgcn_readlane(bestRot, src);
                     }
                 }
             }

@@ -97,8 +97,7 @@ __device__ __forceinline__ void pose_eval(const Cam& cam, const double* p, bool 
     const double ex = active ? u - ui : 0.0, ey = active ? v - vi : 0.0;
     S.err2 = wsum(ex * ex + ey * ey);
     double m = fmax(fabs(ex), fabs(ey));
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) m = fmax(m, __shfl_xor(m, d, 64));
+    m = wave_allreduce(m, [](double a, double b) { return fmax(a, b); });
     S.rinf = m;
     if (WITH_J) {
         double ju[6], jv[6];

@@ -10,6 +10,7 @@
 // driven from a 16-entry LDS stack: a polygon that needs more than 8 vertices
 // before the clean-up pass can never end with 4, so it is dropped early.
 #include "internal.h"
+#include "wave_reduce.h"
 
 #include <algorithm>
 
@@ -18,12 +19,7 @@ namespace camsync {
 namespace {
 
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        unsigned long long o = __shfl_xor(v, d, 64);
-        v = o > v ? o : v;
-    }
-    return v;
+    return wave_allreduce(v, [](unsigned long long a, unsigned long long b) { return a > b ? a : b; });
 }
 
 struct IPt { int x, y; };

@@ -10,6 +10,7 @@
 // separable weight table exp(-(i/win)^2) is computed on the host so the
 // weights are those of the CPU path bit for bit.
 #include "internal.h"
+#include "wave_reduce.h"
 
 #include <algorithm>
 
@@ -21,9 +22,7 @@ constexpr int kMaxWin = 20;
 constexpr int kMaxPatch = 2 * kMaxWin + 3;
 
 __device__ __forceinline__ double wave_sum_d(double v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-    return v;
+    return wave_allreduce(v, [](double a, double b) { return a + b; });
 }
 
 // getRectSubPix_8u32f for one output element (i,j) of a pw x pw patch.

@@ -8,12 +8,12 @@
 
 #include <hip/hip_runtime.h>
 
+#include "wave_reduce.h"
+
 namespace camsync {
 
 __device__ __forceinline__ double wsum(double v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-    return v;
+    return wave_allreduce(v, [](double a, double b) { return a + b; });
 }
 
 // In-place Cholesky solve of the symmetric positive definite N x N system
