@@ -1,0 +1,141 @@
+#!/usr/bin/env python3
+"""Secondary measurements of SURVEY.md §8(d) that are not the bench line (bench.py prints that one):
+
+  * configs[2] on one GPU: detection of 3840x2160 frames with 40 markers each (frames/s, resident input);
+  * config 5: wall latency of `processArucoFromMultipleCameras` for 8 cameras looking at one scene
+    (p50 / p99 over repeated frame-sets, 1280x720 and 1920x1080), host frames in, Python mirror API;
+  * the PCIe-inclusive rate of the host-buffer entry point.
+
+    python bench_extra.py [--frames4k 256] [--sets 200] > profiles/rNN_extra.json
+
+Synthetic frames from this repository's renderer (no dataset, no network).  One JSON object on stdout.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames4k", type=int, default=0,
+                    help="frames of the 4K configuration (0 = skip: 4K is validated at batch 1 by tests/test_gpu_edges.py; a 256-frame 4K batch has not been validated yet)")
+    ap.add_argument("--sets", type=int, default=200)
+    args = ap.parse_args()
+
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench_extra.py needs a GPU (libcamsync_hip has no CPU fallback)")
+    dev = torch.device("cuda", 0)
+    from cameracalibration_amd import _hip, synth
+    from cameracalibration_amd.camera_sync import aruco as A
+    from cameracalibration_amd.camera_sync.camera import Camera
+    from tests import _data
+
+    out = {}
+
+    if args.frames4k > 0:
+        # ---- configs[2], one GPU: 4K, 40 markers per frame ----
+        H, W = 2160, 3840
+        K4 = np.array([[2800.0, 0, 1920.0], [0, 2800.0, 1080.0], [0, 0, 1.0]])
+        pool = 4
+        clean = torch.stack([synth.grid_frame(i, K4, device=dev, ss=2)[0][:, :, 0].to(torch.float32) for i in range(pool)])
+        n = args.frames4k
+        frames = torch.empty((n, H, W, 3), dtype=torch.uint8, device=dev)
+        g = torch.Generator(device=dev).manual_seed(7)
+        for b0 in range(0, n, 16):
+            nb = min(16, n - b0)
+            idx = torch.arange(b0, b0 + nb, device=dev) % pool
+            noise = torch.randn((nb, H, W, 3), generator=g, device=dev, dtype=torch.float32) * 4.0
+            frames[b0:b0 + nb] = (clean[idx][..., None] + noise).round_().clamp_(0, 255).to(torch.uint8)
+        MM = 64
+        d_ids = torch.full((n, MM), -1, dtype=torch.int32, device=dev)
+        d_cor = torch.zeros((n, MM, 4, 2), dtype=torch.float32, device=dev)
+        d_cnt = torch.zeros((n,), dtype=torch.int32, device=dev)
+        d_rv = torch.zeros((n, 3), dtype=torch.float64, device=dev)
+        d_tv = torch.zeros((n, 3), dtype=torch.float64, device=dev)
+        d_ok = torch.zeros((n,), dtype=torch.uint8, device=dev)
+        ctx = _hip.Context(H, W, max_batch=n, device=0)
+        # anchors: the first four markers of pose 0's sheet (id, top-left x, y, side), corners in sheet millimetres
+        sheet0 = synth.sheet_grid(np.random.default_rng(4321))
+        anchors = [int(m[0]) for m in sheet0[:4]]
+        anchor_obj = np.array([[[x, y, 0], [x + sz, y, 0], [x + sz, y - sz, 0], [x, y - sz, 0]] for (_, x, y, sz) in sheet0[:4]],
+                              np.float32)
+
+        def step4k():
+            ctx.detect_pnp_resident(frames.data_ptr(), n, H, W, 3, anchors, anchor_obj, K4, np.zeros(5), MM,
+                                    d_ids.data_ptr(), d_cor.data_ptr(), d_cnt.data_ptr(), d_rv.data_ptr(),
+                                    d_tv.data_ptr(), d_ok.data_ptr())
+
+        try:
+            step4k()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                step4k()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / 3
+            out["config2_4k_one_gpu"] = {
+                "frames": n, "frames_per_s": n / dt, "ms_per_frame": dt / n * 1e3,
+                "mean_markers_per_frame": float(d_cnt.to(torch.float64).mean().item()),
+                "hbm_frac_k1k3_11B_per_px": n / dt * H * W * 11.0 / 8e12,
+                "note": "detect + PnP on 4 sheet markers, resident input, %d rendered poses x per-frame noise" % pool}
+        except Exception as e:  # keep the other measurements
+            out["config2_4k_one_gpu"] = {"error": str(e)}
+        del frames, clean, ctx
+        torch.cuda.empty_cache()
+
+    # ---- config 5: 8 cameras, one scene, processArucoFromMultipleCameras (host frames, mirror API) ----
+    K, dist = _data.calibration("Logitec_robot_1920-1080_10.npz")
+    for (h, w, camname, focus) in ((720, 1280, "Logitec_A", 0), (1080, 1920, "Logitec_robot", 10)):
+        cams = [Camera(camname, -1, focus=focus, resolution=(w, h)) for _ in range(8)]
+        Kc = np.asarray(cams[0].mtx, dtype=np.float64)
+        views = [synth.v1_frame(100 + i, Kc, H=h, W=w, device=dev, ss=2)[0].cpu().numpy() for i in range(8)]
+        sheet = A.getArucosFromPaper(1)
+        fixed = [sheet[i] for i in (10, 11, 14, 15)]
+        moving = {12: sheet[12], 13: sheet[13]}
+        lat = []
+        try:
+            A.processArucoFromMultipleCameras(fixed, moving, cams, views)
+            for _ in range(args.sets):
+                t0 = time.perf_counter()
+                A.processArucoFromMultipleCameras(fixed, moving, cams, views)
+                lat.append((time.perf_counter() - t0) * 1e3)
+            lat = np.array(lat)
+            out["config5_8cams_%dx%d" % (w, h)] = {
+                "sets": args.sets, "p50_ms": float(np.percentile(lat, 50)), "p99_ms": float(np.percentile(lat, 99)),
+                "note": "8 host frames per set, per-camera loop of the mirror API (detect + PnP + locate), "
+                        "includes the host-to-device copies"}
+        except Exception as e:
+            out["config5_8cams_%dx%d" % (w, h)] = {"error": "%s: %s" % (type(e).__name__, e)}
+
+    # ---- one launch sequence for the same 8 frames (detectArucoBatch + processArucoBatch) ----
+    try:
+        h, w = 1080, 1920
+        views = np.stack([synth.v1_frame(100 + i, K, H=h, W=w, device=dev, ss=2)[0].cpu().numpy() for i in range(8)])
+        sheet = A.getArucosFromPaper(1)
+        fixed = [sheet[i] for i in (10, 11, 14, 15)]
+        A.processArucoBatch(fixed, views, K, dist)
+        lat = []
+        for _ in range(args.sets):
+            t0 = time.perf_counter()
+            A.processArucoBatch(fixed, views, K, dist)
+            lat.append((time.perf_counter() - t0) * 1e3)
+        lat = np.array(lat)
+        out["batch8_1920x1080_processArucoBatch"] = {
+            "sets": args.sets, "p50_ms": float(np.percentile(lat, 50)), "p99_ms": float(np.percentile(lat, 99)),
+            "note": "the 8 frames as one batch: one copy, one launch sequence, camera poses only"}
+    except Exception as e:
+        out["batch8_1920x1080_processArucoBatch"] = {"error": "%s: %s" % (type(e).__name__, e)}
+
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
