@@ -200,18 +200,25 @@ int enqueue_detect(camsync_ctx* c, const uint8_t* d_in, int B, int H, int W, int
     StageTimer t(c);
     launch_gray_thresh(cfg, b, B, C, c->stream);
     t.mark(0);
+    debug_stage(c->stream, "gray_threshold");
     launch_contour_starts(cfg, b, B, c->stream);
     t.mark(1);
+    debug_stage(c->stream, "contour_starts");
     launch_trace(cfg, b, c->stream);
     t.mark(2);
+    debug_stage(c->stream, "trace");
     launch_quad_fit(cfg, b, B, c->stream);
     t.mark(3);
+    debug_stage(c->stream, "quad_fit");
     launch_identify(cfg, b, B, c->stream);
     t.mark(4);
+    debug_stage(c->stream, "identify");
     launch_select(cfg, b, B, c->stream);
     t.mark(5);
+    debug_stage(c->stream, "select");
     launch_subpix(cfg, b, B, c->stream);
     t.mark(6);
+    debug_stage(c->stream, "subpix");
     c->lastB = B;
     c->lastH = H;
     c->lastW = W;
@@ -608,7 +615,9 @@ int camsync_detect_pnp_resident(camsync_ctx* c, const uint8_t* d_frames, int B, 
         a.obj = c->d_obj; a.img = c->d_img; a.npts = c->d_npts; a.B = nb; a.N = 64;
         a.K = c->d_K; a.dist = c->d_dist; a.ndist = ndist; a.perFrameCam = 0; a.refine = 1;
         a.rvec = d_rvec + (size_t)b0 * 3; a.tvec = d_tvec + (size_t)b0 * 3; a.ok = d_pose_ok + b0; a.mae = nullptr; a.rmse = nullptr;
+        debug_stage(c->stream, "gather_anchors");
         launch_pnp(a, c->stream);
+        debug_stage(c->stream, "pnp");
         if (c->timing) (void)hipEventRecord(c->ev[8], c->stream);
         HIPCHK(c, hipMemcpy2DAsync(d_ids + (size_t)b0 * max_markers, sizeof(int32_t) * max_markers, c->buf.outIds,
                                    sizeof(int32_t) * kMaxMarkerOut, sizeof(int32_t) * mm, nb, hipMemcpyDeviceToDevice, c->stream));

@@ -2,6 +2,9 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
 #include <stdint.h>
 #include "../../include/camsync.h"
 
@@ -89,6 +92,19 @@ constexpr int kTraceWaves = 256 * 16;  // persistent single-wave workgroups of t
 constexpr int kCkStride = 256;         // a checkpoint (and a store task) every this many points
 constexpr int kTailPairs = 8;           // a decide wave with at most this many borders left hands them to the tail pass
 constexpr int kCkMax = 32;             // checkpoints per direction: covers borders up to 2 * 32 * 256 points
+
+// Debugging aid (environment variable CAMSYNC_DEBUG_STAGES): wait for the stream after every kernel of the detection
+// sequence and report it on stderr, so that a failing kernel is named.  Off: one getenv at the first call.
+inline bool debug_stages() {
+    static const bool on = std::getenv("CAMSYNC_DEBUG_STAGES") != nullptr;
+    return on;
+}
+inline void debug_stage(hipStream_t st, const char* name) {
+    if (!debug_stages()) return;
+    const hipError_t e = hipStreamSynchronize(st);
+    std::fprintf(stderr, "[camsync] %s: %s\n", name, hipGetErrorString(e));
+    std::fflush(stderr);
+}
 
 struct Counters {
     unsigned int nCand;

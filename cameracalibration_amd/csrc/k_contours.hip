@@ -1105,12 +1105,15 @@ void launch_trace(const DetCfg& c, const DetBuffers& b, hipStream_t st) {
     hipLaunchKernelGGL(k_trace_short, dim3(256 * 8), dim3(256), 0, st, b.planes, c, b.cand, b.candCap, b.candLong,
                        b.contours, b.contourCap, b.poolCap, b.tasks, b.taskCap, b.counters);
     // persistent: 10 single-wave workgroups per CU (16 KiB of LDS each)
+    debug_stage(st, "trace_short");
     // (the start list is free after the short pass: it holds the tail records)
     TailRec* tail = reinterpret_cast<TailRec*>(b.cand);
     hipLaunchKernelGGL(k_trace_decide<false>, dim3(kTraceWaves), dim3(64), 0, st, b.planes, c, b.candLong, b.candCap, tail,
                        b.contours, b.contourCap, b.poolCap, b.tasks, b.taskCap, b.ckpt, b.counters);
+    debug_stage(st, "trace_decide");
     hipLaunchKernelGGL(k_trace_decide<true>, dim3(kTraceWaves * kTailPairs * 2 / kTailLanes), dim3(64), 0, st, b.planes, c, b.candLong,
                        b.candCap, tail, b.contours, b.contourCap, b.poolCap, b.tasks, b.taskCap, b.ckpt, b.counters);
+    debug_stage(st, "trace_decide_tail");
     hipLaunchKernelGGL(k_trace_store, dim3(kTraceWaves), dim3(64), 0, st, b.planes, c, b.tasks, b.taskCap, b.pool, b.counters);
 }
 

@@ -30,6 +30,10 @@ __global__ __launch_bounds__(64) void k_quad_fit(const ContourRec* __restrict__ 
                                                  int* __restrict__ qcount, Counters* __restrict__ ctr, DetCfg cfg) {
     __shared__ int s_stack[32][2];
     __shared__ IPt s_dst[16];
+    // the points of the contour, when they fit: every Douglas-Peucker pass depends on the result of the one
+    // before, so with the points in HBM/L2 a contour costs a chain of about ten memory latencies
+    constexpr int kCacheN = 1024;
+    __shared__ uint32_t s_pts[kCacheN];
     const int lane = threadIdx.x;
     const unsigned int nC = min(ctr->nContours, contourCap);
     for (unsigned int ci = blockIdx.x; ci < nC; ci += gridDim.x) {
@@ -37,7 +41,12 @@ __global__ __launch_bounds__(64) void k_quad_fit(const ContourRec* __restrict__ 
         const ContourRec rec = contours[ci];
         const int n = (int)rec.len;
         if (n == 0) continue;  // a slot a border-follower wave reserved and did not use
-        const uint32_t* __restrict__ P = pool + rec.off;
+        const uint32_t* __restrict__ G = pool + rec.off;
+        const bool cached = n <= kCacheN;
+        if (cached)
+            for (int i = lane; i < n; i += 64) s_pts[i] = G[i];
+        __syncthreads();
+        auto P = [&](int i) { return cached ? s_pts[i] : G[i]; };
         double eps = (double)n * cfg.accuracyRate;
         eps *= eps;
 
@@ -46,12 +55,12 @@ __global__ __launch_bounds__(64) void k_quad_fit(const ContourRec* __restrict__ 
         bool le_eps = false;
         for (int it = 0; it < 3; it++) {
             pos = (pos + rs) % n;
-            const IPt sp = unpack_pt(P[pos]);
+            const IPt sp = unpack_pt(P(pos));
             unsigned long long best = 0;
             for (int j = 1 + lane; j < n; j += 64) {
                 int idx = pos + j;
                 if (idx >= n) idx -= n;
-                const IPt p = unpack_pt(P[idx]);
+                const IPt p = unpack_pt(P(idx));
                 const long long dx = p.x - sp.x, dy = p.y - sp.y;
                 const unsigned long long d = (unsigned long long)(dx * dx + dy * dy);
                 const unsigned long long key = (d << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)j);
@@ -74,7 +83,7 @@ __global__ __launch_bounds__(64) void k_quad_fit(const ContourRec* __restrict__ 
             }
             top = 2;
         } else {
-            if (lane == 0) s_dst[0] = unpack_pt(P[pos]);
+            if (lane == 0) s_dst[0] = unpack_pt(P(pos));
             cnt = 1;
         }
         __syncthreads();
@@ -84,8 +93,8 @@ __global__ __launch_bounds__(64) void k_quad_fit(const ContourRec* __restrict__ 
             top--;
             const int a = s_stack[top][0], b = s_stack[top][1];
             __syncthreads();
-            const IPt sp = unpack_pt(P[a]);
-            const IPt ep = unpack_pt(P[b]);
+            const IPt sp = unpack_pt(P(a));
+            const IPt ep = unpack_pt(P(b));
             int first = a + 1;
             if (first >= n) first = 0;
             bool le;
@@ -98,7 +107,7 @@ __global__ __launch_bounds__(64) void k_quad_fit(const ContourRec* __restrict__ 
                 for (int t = lane; t < L; t += 64) {
                     int idx = first + t;
                     if (idx >= n) idx -= n;
-                    const IPt p = unpack_pt(P[idx]);
+                    const IPt p = unpack_pt(P(idx));
                     long long d = (long long)(p.y - sp.y) * dx - (long long)(p.x - sp.x) * dy;
                     if (d < 0) d = -d;
                     const unsigned long long key = ((unsigned long long)d << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)t);
