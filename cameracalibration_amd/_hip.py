@@ -90,6 +90,8 @@ def load_library() -> C.CDLL:
         lib.camsync_debug_quads.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp]
         lib.camsync_debug_contours.argtypes = [vp, i32, i32, vp, vp, vp, vp]
         lib.camsync_debug_points.argtypes = [vp, i32, i32, vp]
+        lib.camsync_debug_limit_capacity.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32]
+        lib.camsync_debug_restore_capacity.argtypes = [vp]
         lib.camsync_pnp_batch.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, vp, vp, vp]
         lib.camsync_ippe_square_batch.argtypes = [vp, vp, vp, i32, vp, vp, i32, i32, vp, vp, vp]
         lib.camsync_detect_pnp_batch.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp, i32, i32,
@@ -248,6 +250,13 @@ class Context:
         if n < 0:
             self._check(n)
         return xy[:min(n, cap)]
+
+    def debug_limit_capacity(self, contours=0, points=0, tasks=0):
+        """Testing aid: lower the list capacities (0 = unchanged) so that one small frame overflows them."""
+        self._check(self._lib.camsync_debug_limit_capacity(self._h, contours, points, tasks))
+
+    def debug_restore_capacity(self):
+        self._check(self._lib.camsync_debug_restore_capacity(self._h))
 
     # -- pose ----------------------------------------------------------
     def pnp(self, obj, img, npts, K, dist):

@@ -22,6 +22,7 @@ struct camsync_ctx {
     camsync_params params;
     int dictN = 0, markerSize = 4, maxCorrectionBits = 1;
     std::string err;
+    unsigned int allocContourCap = 0, allocPoolCap = 0, allocTaskCap = 0;  // set once camsync_debug_limit_capacity lowered them
 
     // device scratch
     uint8_t* d_in = nullptr;   // staging for host frames (lazy)
@@ -349,11 +350,13 @@ int camsync_create(camsync_ctx** out, int device, int max_h, int max_w, int max_
     HIPCHK(c, dalloc(&b.cand, b.candCap));
     HIPCHK(c, dalloc(&b.candLong, b.candCap));
     // (+ the blocks the persistent border-follower waves reserve and may leave partly unused)
-    b.contourCap = (unsigned)std::min<size_t>(B * 4096 + (size_t)(kTraceWaves + 8192) * 32, 0x7FFFFFFFu);
+    // (decide pass: kTraceWaves waves + kTraceWaves * kTailPairs / 32 tail waves; short pass: 8192 waves)
+    constexpr size_t kLongWaves = (size_t)kTraceWaves + (size_t)kTraceWaves * kTailPairs / 32;
+    b.contourCap = (unsigned)std::min<size_t>(B * 4096 + (kLongWaves + 8192) * 32, 0x7FFFFFFFu);
     HIPCHK(c, dalloc(&b.contours, b.contourCap));
-    b.poolCap = (unsigned)std::min<size_t>(B * (size_t)262144 + (size_t)kTraceWaves * 16384 + (size_t)8192 * 2048, 0x7FFFFFFFu);
+    b.poolCap = (unsigned)std::min<size_t>(B * std::max<size_t>(262144, px / 8) + kLongWaves * 16384 + (size_t)8192 * 2048, 0x7FFFFFFFu);
     HIPCHK(c, dalloc(&b.pool, b.poolCap));
-    b.taskCap = (unsigned)std::min<size_t>((size_t)b.contourCap * 2 + b.poolCap / kCkStride + (size_t)kTraceWaves * 128 + (size_t)8192 * 32, 0x7FFFFFFFu);
+    b.taskCap = (unsigned)std::min<size_t>((size_t)b.contourCap * 2 + b.poolCap / kCkStride + kLongWaves * 128 + (size_t)8192 * 32, 0x7FFFFFFFu);
     HIPCHK(c, dalloc(&b.tasks, b.taskCap));
     HIPCHK(c, dalloc(&b.ckpt, (size_t)kTraceWaves * 32 * 2 * kCkMax));
     HIPCHK(c, dalloc(&b.quads, B * kQuadCap));
@@ -633,6 +636,30 @@ int camsync_detect_pnp_resident(camsync_ctx* c, const uint8_t* d_frames, int B, 
         if (rc) return rc;
     }
     if (overflowSeen) return fail(c, CAMSYNC_E_CAPACITY, "detection scratch overflow (mask 0x%x)", overflowSeen);
+    return CAMSYNC_OK;
+}
+
+int camsync_debug_limit_capacity(camsync_ctx* c, unsigned int contours, unsigned int points, unsigned int tasks) {
+    if (!c) return CAMSYNC_E_ARG;
+    DetBuffers& b = c->buf;
+    if (!c->allocContourCap) {
+        c->allocContourCap = b.contourCap;
+        c->allocPoolCap = b.poolCap;
+        c->allocTaskCap = b.taskCap;
+    }
+    if (contours) b.contourCap = std::min(contours, c->allocContourCap);
+    if (points) b.poolCap = std::min(points, c->allocPoolCap);
+    if (tasks) b.taskCap = std::min(tasks, c->allocTaskCap);
+    return CAMSYNC_OK;
+}
+
+int camsync_debug_restore_capacity(camsync_ctx* c) {
+    if (!c) return CAMSYNC_E_ARG;
+    if (c->allocContourCap) {
+        c->buf.contourCap = c->allocContourCap;
+        c->buf.poolCap = c->allocPoolCap;
+        c->buf.taskCap = c->allocTaskCap;
+    }
     return CAMSYNC_OK;
 }
 

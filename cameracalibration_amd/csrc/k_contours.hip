@@ -79,11 +79,11 @@ __global__ __launch_bounds__(256) void k_contour_starts(const uint32_t* __restri
             unsigned int g = 0;
             if (lane == 0) g = atomicAdd(&ctr->nCand, staged);
             g = __builtin_amdgcn_readfirstlane(g);
-            if (g + staged > candCap) {
-                if (lane == 0) atomicOr(&ctr->overflow, 1u);
-            } else {
-                for (unsigned int k = lane; k < staged; k += 64) cand[g + k] = stage[k];
-            }
+            // (a full list fails the call with CAMSYNC_E_CAPACITY; the part that fits is still written, because the
+            // next pass reads every entry below min(count, capacity))
+            if (g + staged > candCap && lane == 0) atomicOr(&ctr->overflow, 1u);
+            const unsigned int fit = g >= candCap ? 0u : min(staged, candCap - g);
+            for (unsigned int k = lane; k < fit; k += 64) cand[g + k] = stage[k];
             staged = 0;
         }
     };
@@ -571,6 +571,9 @@ struct WaveQueue {
 
 struct WaveAlloc {
     unsigned int cur = 0, end = 0;
+    // set when a refill did not fit: the entries between the counter's old value and the capacity belong to
+    // nobody, and the caller must make them read as empty (the next pass looks at every entry below the capacity)
+    unsigned int orphanLo = 0, orphanHi = 0;
     // uniform call: reserve `need` consecutive entries; refills from the global counter by blocks.
     // Returns ~0u (and raises the overflow bit) when the list is full.  `left` receives the abandoned tail
     // [left.x, left.y) of the previous block when a refill happens (the caller marks those entries empty).
@@ -586,6 +589,10 @@ struct WaveAlloc {
             if (b + sz > cap) {
                 if (lane == 0) atomicOr(&ctr->overflow, ovfBit);
                 cur = end = 0;
+                if (b < cap) {
+                    orphanLo = b;
+                    orphanHi = cap;
+                }
                 return ~0u;
             }
             cur = b;
@@ -609,6 +616,19 @@ __device__ __forceinline__ void mark_empty_tasks(StoreTask* __restrict__ tasks, 
         StoreTask k;
         k.plane = 0; k.state = 0; k.dst = 0; k.count = 0;
         tasks[i] = k;
+    }
+}
+
+// after a failed reservation: the entries nobody owns (see WaveAlloc) read as empty
+__device__ __forceinline__ void adopt_orphans(WaveAlloc& slotA, WaveAlloc& taskA, ContourRec* __restrict__ contours,
+                                              StoreTask* __restrict__ tasks, int lane) {
+    if (slotA.orphanHi > slotA.orphanLo) {
+        mark_empty_contours(contours, slotA.orphanLo, slotA.orphanHi, lane);
+        slotA.orphanLo = slotA.orphanHi = 0;
+    }
+    if (taskA.orphanHi > taskA.orphanLo) {
+        mark_empty_tasks(tasks, taskA.orphanLo, taskA.orphanHi, lane);
+        taskA.orphanLo = taskA.orphanHi = 0;
     }
 }
 
@@ -640,11 +660,9 @@ __global__ __launch_bounds__(256) void k_trace_short(const uint32_t* __restrict_
             unsigned int g = 0;
             if (lane == 0) g = atomicAdd(&ctr->nLong, staged);
             g = __builtin_amdgcn_readfirstlane(g);
-            if (g + staged > candCap) {
-                if (lane == 0) atomicOr(&ctr->overflow, 1u);
-            } else {
-                for (unsigned int k = lane; k < staged; k += 64) candLong[g + k] = stage[k];
-            }
+            if (g + staged > candCap && lane == 0) atomicOr(&ctr->overflow, 1u);
+            const unsigned int fit = g >= candCap ? 0u : min(staged, candCap - g);  // see k_contour_starts
+            for (unsigned int k = lane; k < fit; k += 64) candLong[g + k] = stage[k];
             staged = 0;
         }
     };
@@ -729,6 +747,13 @@ __global__ __launch_bounds__(256) void k_trace_short(const uint32_t* __restrict_
             const unsigned int off = poolA.take(len, kShortPoolBlock, &ctr->nPool, poolCap, 4u, ctr, lane, left);
             const unsigned int slot = slotA.take(1, kSlotBlock, &ctr->nContours, contourCap, 2u, ctr, lane, left);
             const unsigned int t0 = taskA.take(1, kSlotBlock, &ctr->nTasks, taskCap, 64u, ctr, lane, left);
+            if (off == ~0u || slot == ~0u || t0 == ~0u) {
+                // a list is full (the call will fail with CAMSYNC_E_CAPACITY): what was obtained must still read
+                // as empty, the later passes look at every reserved entry
+                if (slot != ~0u) mark_empty_contours(contours, slot, slot + 1, lane);
+                if (t0 != ~0u) mark_empty_tasks(tasks, t0, t0 + 1, lane);
+                adopt_orphans(slotA, taskA, contours, tasks, lane);
+            }
             if (lane == l && off != ~0u && slot != ~0u && t0 != ~0u) {
                 myOff = off;
                 mySlot = slot;
@@ -957,6 +982,13 @@ __global__ __launch_bounds__(64) void k_trace_decide(const uint32_t* __restrict_
             const unsigned int slot = slotA.take(1, kSlotBlock, &ctr->nContours, contourCap, 2u, ctr, lane, left);
             const unsigned int t0 = taskA.take(2 * ntl, kTaskBlock, &ctr->nTasks, taskCap, 64u, ctr, lane, left);
             mark_empty_tasks(tasks, left.x, left.y, lane);
+            if (off == ~0u || slot == ~0u || t0 == ~0u) {
+                // a list is full (the call will fail with CAMSYNC_E_CAPACITY): what was obtained must still read
+                // as empty, the later passes look at every reserved entry
+                if (slot != ~0u) mark_empty_contours(contours, slot, slot + 1, lane);
+                if (t0 != ~0u) mark_empty_tasks(tasks, t0, t0 + 2 * ntl, lane);
+                adopt_orphans(slotA, taskA, contours, tasks, lane);
+            }
             if ((lane & ~1) == l && off != ~0u && slot != ~0u && t0 != ~0u) {
                 myOff = off;
                 mySlot = slot;

@@ -125,6 +125,13 @@ int camsync_debug_contours(camsync_ctx* ctx, int frame, int max_contours, int32_
                            int32_t* start_key, int32_t* is_hole, int32_t* length);
 int camsync_debug_points(camsync_ctx* ctx, int frame, int max_points, int32_t* xy);
 
+/* Testing aid, no counterpart in the reference: lower the capacities of the contour-record, contour-point and
+ * store-task lists of a context (0 = leave as is; values above the allocated capacity are clamped to it), so that
+ * the overflow paths, which otherwise need gigabytes of contours, can be exercised with one small frame.
+ * camsync_debug_restore_capacity puts the allocated capacities back. */
+int camsync_debug_limit_capacity(camsync_ctx* ctx, unsigned int contours, unsigned int points, unsigned int tasks);
+int camsync_debug_restore_capacity(camsync_ctx* ctx);
+
 /* ---- pose ----------------------------------------------------------- */
 
 /* cv.solvePnP(ITERATIVE) followed by cv.solvePnPRefineLM, batched

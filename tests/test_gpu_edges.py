@@ -55,6 +55,27 @@ def test_capacity_overflow_is_loud():
     ctx.detect(np.zeros((480, 640, 3), np.uint8))  # the context stays usable
 
 
+@pytest.mark.parametrize("limit", [dict(points=2000), dict(points=17000), dict(contours=20), dict(tasks=100),
+                                   dict(contours=37, tasks=61)])
+def test_contour_list_overflow_is_loud_and_harmless(limit):
+    """The contour, point and store-task lists are sized for thousands of frames, so one small frame can only fill
+    them when their capacities are lowered (testing aid of the C ABI).  Every overflow must end in
+    CAMSYNC_E_CAPACITY -- the passes after the border followers read every reserved entry, so entries that
+    were reserved but not written must read as empty -- and leave the context usable."""
+    K, _ = _data.calibration("Logitec_robot_1920-1080_10.npz")
+    frame = synth.v1_frame(1, K, ss=2)[0].numpy()[300:540, 600:920].copy()
+    ctx = _hip.Context(240, 320, 1)
+    want = ctx.detect(frame)
+    ctx.debug_limit_capacity(**limit)
+    with pytest.raises(_hip.CamsyncError) as e:
+        ctx.detect(frame)
+    assert e.value.code == _hip.E_CAPACITY
+    ctx.debug_restore_capacity()
+    got = ctx.detect(frame)
+    for a, b in zip(want, got):
+        assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("hw", [(32, 32), (33, 40), (47, 104), (240, 320), (481, 648)])
 def test_small_and_odd_sizes(hw):
     """Smallest supported frame, heights that are not multiples of 32, widths that are multiples of 8 only."""
