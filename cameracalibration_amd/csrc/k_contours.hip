@@ -1040,7 +1040,8 @@ __global__ __launch_bounds__(64) void k_trace_decide(const uint32_t* __restrict_
 // Write the points of the accepted borders: one lane per store task.
 __global__ __launch_bounds__(64) void k_trace_store(const uint32_t* __restrict__ planes, DetCfg cfg,
                                                     const StoreTask* __restrict__ tasks, unsigned int taskCap,
-                                                    uint32_t* __restrict__ pool, Counters* __restrict__ ctr) {
+                                                    uint32_t* __restrict__ pool, unsigned int poolCap,
+                                                    Counters* __restrict__ ctr) {
     __shared__ __align__(8) uint32_t tile[kTileWords];
     const int lane = threadIdx.x;
     const unsigned int n = min(ctr->nTasks, taskCap);
@@ -1071,7 +1072,7 @@ __global__ __launch_bounds__(64) void k_trace_store(const uint32_t* __restrict__
                     oidx = k.dst;
                     nq = 0;
                     win.valid = false;
-                    active = left > 0;
+                    active = left > 0 && left <= kCkStride && k.dst < poolCap && k.count <= poolCap - k.dst;  // (empty or not a task: skipped)
                 } else if (queue.empty()) {
                     exhausted = true;
                 }
@@ -1146,7 +1147,7 @@ void launch_trace(const DetCfg& c, const DetBuffers& b, hipStream_t st) {
     hipLaunchKernelGGL(k_trace_decide<true>, dim3(kTraceWaves * kTailPairs * 2 / kTailLanes), dim3(64), 0, st, b.planes, c, b.candLong,
                        b.candCap, tail, b.contours, b.contourCap, b.poolCap, b.tasks, b.taskCap, b.ckpt, b.counters);
     debug_stage(st, "trace_decide_tail");
-    hipLaunchKernelGGL(k_trace_store, dim3(kTraceWaves), dim3(64), 0, st, b.planes, c, b.tasks, b.taskCap, b.pool, b.counters);
+    hipLaunchKernelGGL(k_trace_store, dim3(kTraceWaves), dim3(64), 0, st, b.planes, c, b.tasks, b.taskCap, b.pool, b.poolCap, b.counters);
 }
 
 }  // namespace camsync

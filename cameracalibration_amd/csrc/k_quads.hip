@@ -40,7 +40,7 @@ __global__ __launch_bounds__(64) void k_quad_fit(const ContourRec* __restrict__ 
         __syncthreads();
         const ContourRec rec = contours[ci];
         const int n = (int)rec.len;
-        if (n == 0) continue;  // a slot a border-follower wave reserved and did not use
+        if (n <= 0 || n > cfg.maxPerim) continue;  // a slot a border-follower wave reserved and did not use (kept contours never exceed maxPerim)
         const uint32_t* __restrict__ G = pool + rec.off;
         const bool cached = n <= kCacheN;
         if (cached)
