@@ -25,13 +25,16 @@
 //       dropped as soon as either tracer meets a crack with a smaller raster
 //       key (it is not the canonical start) or the border closes below the
 //       minimum perimeter.  Noise specks and false starts end here.
-//   (3) Candidates still alive go to a work queue.  k_trace_tile<false> is a
-//       persistent kernel whose lanes each follow one long border inside a
-//       private LDS window of the plane and fetch the next border from the
-//       queue when done; borders within the perimeter bounds get a slot in the
-//       point pool.
-//   (4) k_trace_tile<true> follows the accepted borders once more the same way
-//       to store their points.
+//   (3) Candidates still alive go to a work queue.  k_trace_decide<false> is a
+//       persistent kernel: two lanes share a border, one follows it forwards and
+//       one backwards inside private LDS windows of the plane, until they meet
+//       (length known) or one of them proves that the start is not canonical;
+//       borders within the perimeter bounds get a record, space in the point
+//       pool and are cut into store tasks of at most 256 points.  Waves left
+//       with a few very long borders hand them to k_trace_decide<true>, which
+//       packs them 32 to a wave.
+//   (4) k_trace_store re-follows every store task from its recorded state and
+//       writes the points to their final place.
 // The traces only read the image, so they are independent of each other.
 #include "internal.h"
 
@@ -358,71 +361,7 @@ struct Tracer {
     }
 };
 
-// Follow the candidate's border for at most `budget` forward steps, in lock-step with the mirrored tracer.
-// Returns  >0  the border closed with that many points (it is a canonical start),
-//           0  the candidate is not a canonical start (dropped),
-//          -1  the budget ran out first (undecided).
-__device__ int probe_border(const uint32_t* __restrict__ plane, int WS, int W, int x0, int y0, bool isHole, int budget) {
-    const int startKey = y0 * W + x0;
-    Tracer<false> fw;
-    Tracer<true> bw;
-    if (!fw.init(plane, WS, x0, y0, isHole)) return 1;
-    bool bwActive = bw.init(plane, WS, x0, y0, isHole);
-    int count = 0;
-    for (;;) {
-        int px, py;
-        bool east;
-        const bool closed = fw.step(plane, WS, px, py, east);
-        if ((isHole ? east : true) && py * W + px < startKey) return 0;
-        count++;
-        if (closed) return count;
-        if (count >= budget) return -1;
-        if (bwActive) {
-            const bool bclosed = bw.step(plane, WS, px, py, east);
-            if ((isHole ? east : true) && py * W + px < startKey) return 0;
-            if (bclosed) bwActive = false;
-        }
-    }
-}
-
-// Reserve pool space and a contour record; returns the pool offset, or ~0u when a list is full.
-__device__ __forceinline__ unsigned int emit_contour(uint64_t c, int len, ContourRec* __restrict__ contours,
-                                                     unsigned int contourCap, unsigned int poolCap, Counters* __restrict__ ctr) {
-    const uint32_t pos = (uint32_t)(c & 0xFFFFFFFFull);
-    const bool hole = (c >> 39) & 1u;
-    const unsigned int off = atomicAdd(&ctr->nPool, (unsigned int)len);
-    if (off + (unsigned int)len > poolCap) {
-        atomicOr(&ctr->overflow, 4u);
-        return ~0u;
-    }
-    const unsigned int slot = atomicAdd(&ctr->nContours, 1u);
-    if (slot >= contourCap) {
-        atomicOr(&ctr->overflow, 2u);
-        return ~0u;
-    }
-    ContourRec r;
-    r.frame = (uint32_t)(c >> 40);
-    r.pos = pos;
-    r.len = (uint32_t)len;
-    r.off = off;
-    r.scale = (uint16_t)((c >> 36) & 7u);
-    r.hole = hole ? 1 : 0;
-    r.scanKey = pos + (hole ? 1u : 0u);
-    contours[slot] = r;
-    return off;
-}
-
 __device__ __forceinline__ uint32_t pack_state(int x, int y, int sdir) { return (uint32_t)x | ((uint32_t)y << 12) | ((uint32_t)sdir << 24); }
-
-// Append `n` store tasks; returns the first slot or ~0u.
-__device__ __forceinline__ unsigned int reserve_tasks(unsigned int n, unsigned int taskCap, Counters* __restrict__ ctr) {
-    const unsigned int t = atomicAdd(&ctr->nTasks, n);
-    if (t + n > taskCap) {
-        atomicOr(&ctr->overflow, 64u);
-        return ~0u;
-    }
-    return t;
-}
 
 // ---- long borders -------------------------------------------------------------------------------
 // Border following is a walk on states (pixel, direction to the predecessor): the successor T(P, s) is
