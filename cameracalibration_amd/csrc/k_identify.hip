@@ -74,6 +74,7 @@ __global__ __launch_bounds__(64) void k_identify(const uint8_t* __restrict__ gra
     const int S = nb * cell;
     const uint8_t* __restrict__ img = gray + (size_t)f * H * W;
     const int imgStride = (S * S + 15) & ~15;
+    const int sy0 = lane / S, sx0 = lane - sy0 * S, sqy = 64 / S, sqx = 64 - sqy * S;
 
     for (int base = blockIdx.x * kIdBatch; base < nq; base += gridDim.x * kIdBatch) {
         const int nbq = min(kIdBatch, nq - base);
@@ -174,8 +175,9 @@ __global__ __launch_bounds__(64) void k_identify(const uint8_t* __restrict__ gra
             const int m2 = cell / 2;
             int sum = 0;
             long long sq = 0;
-            for (int p = lane; p < S * S; p += 64) {
-                const int y = p / S, x = p - y * S;
+            // sample p = lane + 64 k is (y, x); stepping by 64 samples without dividing
+            for (int p = lane, y = sy0, x = sx0; p < S * S; p += 64, y += sqy, x += sqx) {
+                if (x >= S) { x -= S; y++; }
                 int v = 0;
                 if (ok) {
                     const double X0 = mi[0] * 0 + mi[1] * y + mi[2];

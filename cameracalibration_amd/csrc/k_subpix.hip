@@ -122,6 +122,9 @@ __global__ __launch_bounds__(64) void k_subpix(const uint8_t* __restrict__ gray,
         double eps = fmax(cfg.subpixEps, 0.);
         eps *= eps;
 
+        // (row, column) of this lane's first element and of a step of 64 elements, for the patch and the window
+        const int pi0 = lane / pw, pj0 = lane - pi0 * pw, pqi = 64 / pw, pqj = 64 - pqi * pw;
+        const int wi0 = lane / ww, wj0 = lane - wi0 * ww, wqi = 64 / ww, wqj = 64 - wqi * ww;
         const float cTx = mc[2 * corner], cTy = mc[2 * corner + 1];
         float cIx = cTx, cIy = cTy;
         int iter = 0;
@@ -129,14 +132,17 @@ __global__ __launch_bounds__(64) void k_subpix(const uint8_t* __restrict__ gray,
         do {
             const PatchGeom g = patch_geom(cIx, cIy, pw, W, H);
             __syncthreads();
-            for (int e = lane; e < pw * pw; e += 64) {
-                const int i = e / pw, j = e - i * pw;
+            // element e = lane + 64 k of the patch is (row, column) = (i, j); stepping by 64 elements without dividing
+            for (int e = lane, i = pi0, j = pj0; e < pw * pw; e += 64) {
                 s_buf[e] = patch_elem(src, W, H, g, i, j);
+                i += pqi;
+                j += pqj;
+                if (j >= pw) { j -= pw; i++; }
             }
             __syncthreads();
             double a = 0, b = 0, c = 0, bb1 = 0, bb2 = 0;
-            for (int e = lane; e < ww * ww; e += 64) {
-                const int i = e / ww, j = e - i * ww;
+            for (int e = lane, i = wi0, j = wj0; e < ww * ww; e += 64, i += wqi, j += wqj) {
+                if (j >= ww) { j -= ww; i++; }
                 const float* sp = s_buf + (i + 1) * pw + (j + 1);
                 const double m = (double)(float)(et[i] * et[j]);
                 const double tgx = (double)(sp[1] - sp[-1]);
