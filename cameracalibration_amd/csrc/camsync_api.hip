@@ -345,8 +345,8 @@ int camsync_create(camsync_ctx** out, int device, int max_h, int max_w, int max_
     b.bin = nullptr;
     c->planeScales = 3;
     HIPCHK(c, dalloc(&b.planes, B * c->planeScales * plane_words(max_h, (max_w + 31) / 32)));
-    // (at least 2 MiB: after the short pass the start list holds the decide pass's tail records)
-    b.candCap = (unsigned)std::min<size_t>(std::max<size_t>(B * (px / 32), (size_t)kTraceWaves * kTailPairs * 8), 0x7FFFFFFFu);
+    // (at least 2.5 MiB: after the short pass the start list holds the decide pass's tail records, 40 bytes per lane)
+    b.candCap = (unsigned)std::min<size_t>(std::max<size_t>(B * (px / 32), (size_t)kTraceWaves * kTailPairs * 10), 0x7FFFFFFFu);
     HIPCHK(c, dalloc(&b.cand, b.candCap));
     HIPCHK(c, dalloc(&b.candLong, b.candCap));
     // (+ the blocks the persistent border-follower waves reserve and may leave partly unused)
@@ -359,6 +359,12 @@ int camsync_create(camsync_ctx** out, int device, int max_h, int max_w, int max_
     b.taskCap = (unsigned)std::min<size_t>((size_t)b.contourCap * 2 + b.poolCap / kCkStride + kLongWaves * 128 + (size_t)8192 * 32, 0x7FFFFFFFu);
     HIPCHK(c, dalloc(&b.tasks, b.taskCap));
     HIPCHK(c, dalloc(&b.ckpt, (size_t)kTraceWaves * 32 * 2 * kCkMax));
+    // step directions of the borders the decide passes follow (kept or not): one 128-byte chunk per 256 steps and at
+    // least one per border and direction; copy tasks: one per piece of a kept border
+    b.chainCap = (unsigned)std::min<size_t>(B * 2048 + kLongWaves * 256, 0x03FFFFFFu);
+    HIPCHK(c, dalloc(&b.chain, (size_t)b.chainCap * 32));
+    b.copyCap = b.taskCap;
+    HIPCHK(c, dalloc(&b.copies, b.copyCap));
     HIPCHK(c, dalloc(&b.quads, B * kQuadCap));
     HIPCHK(c, dalloc(&b.qcount, B));
     HIPCHK(c, dalloc(&b.counters, 1));
@@ -393,7 +399,7 @@ void camsync_destroy(camsync_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DetBuffers& b = c->buf;
-    void* ptrs[] = {c->d_in, c->d_bin, b.planes, b.gray, b.cand, b.candLong, b.contours, b.pool, b.tasks, b.ckpt, b.quads, b.qcount, b.counters, b.markers,
+    void* ptrs[] = {c->d_in, c->d_bin, b.planes, b.gray, b.cand, b.candLong, b.contours, b.pool, b.tasks, b.ckpt, b.chain, b.copies, b.quads, b.qcount, b.counters, b.markers,
                     b.outIds, b.outCorners, b.rawCorners, b.outCounts, b.outRejected, b.outRejCounts, c->d_dict, c->d_expTab,
                     c->d_obj, c->d_img, c->d_npts, c->d_K, c->d_dist, c->d_rvec, c->d_tvec, c->d_mae, c->d_rmse, c->d_ok,
                     c->d_anchorIds, c->d_anchorObj, c->d_calObj, c->d_calImg, c->cal.intr, c->cal.ext, c->cal.intrTrial,
@@ -649,7 +655,10 @@ int camsync_debug_limit_capacity(camsync_ctx* c, unsigned int contours, unsigned
     }
     if (contours) b.contourCap = std::min(contours, c->allocContourCap);
     if (points) b.poolCap = std::min(points, c->allocPoolCap);
-    if (tasks) b.taskCap = std::min(tasks, c->allocTaskCap);
+    if (tasks) {
+        b.taskCap = std::min(tasks, c->allocTaskCap);
+        b.copyCap = b.taskCap;
+    }
     return CAMSYNC_OK;
 }
 
@@ -659,6 +668,7 @@ int camsync_debug_restore_capacity(camsync_ctx* c) {
         c->buf.contourCap = c->allocContourCap;
         c->buf.poolCap = c->allocPoolCap;
         c->buf.taskCap = c->allocTaskCap;
+        c->buf.copyCap = c->allocTaskCap;
     }
     return CAMSYNC_OK;
 }

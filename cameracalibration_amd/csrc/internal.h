@@ -88,6 +88,15 @@ struct StoreTask {
     uint32_t dst;
     uint32_t count;
 };
+// A piece (at most kCkStride points) of an accepted long border for the copy pass: the border followers record
+// the direction of every step (4 bits) in 128-byte chunks of kCkStride steps, so the points of a piece are its
+// start pixel plus a prefix sum over one chunk, written forwards or (backward half of a border) backwards.
+struct CopyTask {
+    uint32_t chunk;  // index of the 32-word chain chunk
+    uint32_t start;  // x | y << 16 of the piece's first pixel
+    uint32_t dst;    // pool index of that pixel
+    uint32_t n;      // points; bit 31: the following points go to dst - 1, dst - 2, ...
+};
 constexpr int kTraceWaves = 256 * 16;  // persistent single-wave workgroups of the long-border kernels
 constexpr int kCkStride = 256;         // a checkpoint (and a store task) every this many points
 constexpr int kTailPairs = 8;           // a decide wave with at most this many borders left hands them to the tail pass
@@ -118,6 +127,8 @@ struct Counters {
     unsigned int nTasks;    // store tasks appended by the decide passes
     unsigned int qShort;    // work-queue head of the short-border kernel
     unsigned int nTail;     // border pairs handed from the decide pass to its tail pass
+    unsigned int nChain;    // chain chunks handed out
+    unsigned int nCopy;     // copy tasks appended by the decide passes
     unsigned int pad;
 };
 
@@ -135,7 +146,11 @@ struct DetBuffers {
     unsigned int poolCap;
     StoreTask* tasks;
     unsigned int taskCap;
-    uint32_t* ckpt;      // [kTraceWaves][32 pairs][2 directions][kCkMax] checkpoint states of borders in flight
+    uint2* ckpt;         // [kTraceWaves][32 pairs][2 directions][kCkMax] (start pixel, chain chunk) of the pieces of borders in flight
+    uint32_t* chain;     // [chainCap][32] step directions, 8 per word
+    unsigned int chainCap;
+    CopyTask* copies;
+    unsigned int copyCap;
     QuadRec* quads;      // [B,kQuadCap]
     int* qcount;         // [B]
     Counters* counters;

@@ -480,6 +480,7 @@ __device__ __forceinline__ uint32_t from_partner(uint32_t v) {
 // output space (points, contour records, store tasks) in blocks that it sub-allocates itself: the global
 // counters are touched once per block instead of once per border (they are single hot addresses).
 constexpr unsigned int kPoolBlock = 16384, kSlotBlock = 8, kTaskBlock = 128, kDecideBatch = 64, kStoreBatch = 256;
+constexpr unsigned int kChainBlock = 256;  // chain chunks a wave takes from the global counter at a time
 
 struct WaveQueue {
     unsigned int lo = 0, hi = 0;
@@ -558,9 +559,17 @@ __device__ __forceinline__ void mark_empty_tasks(StoreTask* __restrict__ tasks, 
     }
 }
 
+__device__ __forceinline__ void mark_empty_tasks(CopyTask* __restrict__ tasks, unsigned int lo, unsigned int hi, int lane) {
+    for (unsigned int i = lo + lane; i < hi; i += 64) {
+        CopyTask k;
+        k.chunk = 0; k.start = 0; k.dst = 0; k.n = 0;
+        tasks[i] = k;
+    }
+}
 // after a failed reservation: the entries nobody owns (see WaveAlloc) read as empty
+template <class Task>
 __device__ __forceinline__ void adopt_orphans(WaveAlloc& slotA, WaveAlloc& taskA, ContourRec* __restrict__ contours,
-                                              StoreTask* __restrict__ tasks, int lane) {
+                                              Task* __restrict__ tasks, int lane) {
     if (slotA.orphanHi > slotA.orphanLo) {
         mark_empty_contours(contours, slotA.orphanLo, slotA.orphanHi, lane);
         slotA.orphanLo = slotA.orphanHi = 0;
@@ -731,9 +740,9 @@ __global__ __launch_bounds__(256) void k_trace_short(const uint32_t* __restrict_
 // A border in flight, as one lane of its pair holds it (the tail pass resumes from these).
 struct TailRec {
     uint64_t c;
-    uint32_t count, pos, prevState, state0, ck, pad;
+    uint32_t count, pos, prevState, state0, ck, chunk, acc, fail;
 };
-static_assert(sizeof(TailRec) == 32, "tail records are sized against the start list");
+static_assert(sizeof(TailRec) == 40, "tail records are sized against the start list (camsync_create)");
 
 // Decide the long candidates (canonical start? length within bounds?), reserve pool space and cut the accepted
 // borders into store tasks.  Lanes 2p (forward) and 2p + 1 (backward) work on the same candidate.
@@ -748,8 +757,9 @@ __global__ __launch_bounds__(64) void k_trace_decide(const uint32_t* __restrict_
                                                      const uint64_t* __restrict__ candLong, unsigned int candCap,
                                                      TailRec* __restrict__ tail,
                                                      ContourRec* __restrict__ contours, unsigned int contourCap,
-                                                     unsigned int poolCap, StoreTask* __restrict__ tasks, unsigned int taskCap,
-                                                     uint32_t* __restrict__ ckpt, Counters* __restrict__ ctr) {
+                                                     unsigned int poolCap, CopyTask* __restrict__ tasks, unsigned int taskCap,
+                                                     uint2* __restrict__ ckpt, uint32_t* __restrict__ chain, unsigned int chainCap,
+                                                     Counters* __restrict__ ctr) {
     __shared__ __align__(8) uint32_t tile[kTileWords];
     const int lane = threadIdx.x;
     const bool bw = lane & 1;
@@ -757,7 +767,10 @@ __global__ __launch_bounds__(64) void k_trace_decide(const uint32_t* __restrict_
     const int H = cfg.H, W = cfg.W, WS = cfg.WS, S = cfg.nScales;
     const size_t perPlane = plane_words(H, WS);
     uint32_t ckSlot = ((uint32_t)blockIdx.x * 32 + (lane >> 1)) * 2 + (bw ? 1 : 0);
-    uint32_t* myCk = ckpt + (size_t)ckSlot * kCkMax;
+    uint2* myCk = ckpt + (size_t)ckSlot * kCkMax;
+    // the directions of this lane's steps, eight to a word, go to chunks of kCkStride steps (see CopyTask)
+    uint32_t chAcc = 0, chChunk = ~0u;
+    bool chFail = false;
 
     bool active = false, exhausted = false, fresh = false, isHole = false;
     uint64_t c = 0;
@@ -768,7 +781,7 @@ __global__ __launch_bounds__(64) void k_trace_decide(const uint32_t* __restrict_
     win.gx = win.gy = 0;
     win.valid = false;
     WaveQueue queue;
-    WaveAlloc poolA, slotA, taskA;
+    WaveAlloc poolA, slotA, taskA, chainA;
 
     if (RESUME) {
         // one record per lane, pairs adjacent; nothing else to fetch
@@ -789,6 +802,9 @@ __global__ __launch_bounds__(64) void k_trace_decide(const uint32_t* __restrict_
             state0 = r.state0;
             ckSlot = r.ck;
             myCk = ckpt + (size_t)ckSlot * kCkMax;
+            chChunk = r.chunk;
+            chAcc = r.acc;
+            chFail = r.fail != 0;
             active = true;
         }
         exhausted = true;
@@ -811,7 +827,9 @@ __global__ __launch_bounds__(64) void k_trace_decide(const uint32_t* __restrict_
                     r.prevState = prevState;
                     r.state0 = state0;
                     r.ck = ckSlot;
-                    r.pad = 0;
+                    r.chunk = chChunk;
+                    r.acc = chAcc;
+                    r.fail = chFail ? 1u : 0u;
                     tail[2u * base + (unsigned int)__popcll(am & ((1ull << lane) - 1ull))] = r;
                 }
                 break;
@@ -866,6 +884,22 @@ __global__ __launch_bounds__(64) void k_trace_decide(const uint32_t* __restrict_
             }
         }
 
+        // ---- a lane about to take step 0, 256, 512, ... starts a piece: a chain chunk, and the pixel it starts at ----
+        {
+            const bool newPiece = active && (count & (kCkStride - 1)) == 0;
+            const unsigned long long bal = __ballot(newPiece);
+            if (bal) {
+                uint2 unused;
+                const unsigned int base = chainA.take((unsigned int)__popcll(bal), kChainBlock, &ctr->nChain, chainCap, 4u, ctr, lane, unused);
+                if (newPiece) {
+                    chChunk = base == ~0u ? ~0u : base + (unsigned int)__popcll(bal & ((1ull << lane) - 1ull));
+                    chFail = chFail || base == ~0u;
+                    chAcc = 0;
+                    myCk[(count / kCkStride) & (kCkMax - 1)] = make_uint2((uint32_t)cx | ((uint32_t)cy << 16), chChunk);
+                }
+            }
+        }
+
         // res: -1 keep going, 0 drop, > 0 the border closed with that many points
         int res = -1;
         if (active) {
@@ -887,8 +921,11 @@ __global__ __launch_bounds__(64) void k_trace_decide(const uint32_t* __restrict_
             const int key = (int)__umul24((unsigned int)cy, (unsigned int)W) + cx;
             const bool abort = (!isHole || east) && key < startKey;  // smaller key: not the canonical start
             const uint32_t here = pack_state(cx, cy, bw ? q : s);
-            const int hi = count + (bw ? 1 : 0);               // `here` is A_count (forward) or B_(count + 1)
-            if ((hi & (kCkStride - 1)) == 0 && hi) myCk[(hi / kCkStride) & (kCkMax - 1)] = here;
+            chAcc |= (uint32_t)q << (4 * (count & 7));           // step `count` goes in direction q
+            if ((count & 7) == 7) {
+                if (chChunk != ~0u) chain[(size_t)chChunk * 32 + ((count >> 3) & 31)] = chAcc;
+                chAcc = 0;
+            }
             count++;
             cx += fast_dx(q);
             cy += fast_dy(q);
@@ -908,8 +945,10 @@ __global__ __launch_bounds__(64) void k_trace_decide(const uint32_t* __restrict_
             prevState = newState;
         }
         // ---- accepted borders: the wave hands out space border by border (uniform loop), then the pair writes ----
-        const bool accept = res >= cfg.minPerim && res <= cfg.maxPerim;
-        const unsigned int nt = (unsigned int)((count + kCkStride - 1) / kCkStride);  // tasks of this lane's half
+        // (a pair that could not get a chain chunk is dropped: the call fails with CAMSYNC_E_CAPACITY anyway)
+        const bool pairFail = chFail || from_partner(chFail ? 1u : 0u) != 0u;
+        const bool accept = res >= cfg.minPerim && res <= cfg.maxPerim && !pairFail;
+        const unsigned int nt = (unsigned int)((count + kCkStride - 1) / kCkStride);  // pieces of this lane's half
         unsigned int myOff = ~0u, mySlot = ~0u, myTask = ~0u;
         unsigned long long am = __ballot(accept && !bw);
         while (am) {
@@ -919,7 +958,7 @@ __global__ __launch_bounds__(64) void k_trace_decide(const uint32_t* __restrict_
             uint2 left;
             const unsigned int off = poolA.take(len, kPoolBlock, &ctr->nPool, poolCap, 4u, ctr, lane, left);
             const unsigned int slot = slotA.take(1, kSlotBlock, &ctr->nContours, contourCap, 2u, ctr, lane, left);
-            const unsigned int t0 = taskA.take(2 * ntl, kTaskBlock, &ctr->nTasks, taskCap, 64u, ctr, lane, left);
+            const unsigned int t0 = taskA.take(2 * ntl, kTaskBlock, &ctr->nCopy, taskCap, 64u, ctr, lane, left);
             mark_empty_tasks(tasks, left.x, left.y, lane);
             if (off == ~0u || slot == ~0u || t0 == ~0u) {
                 // a list is full (the call will fail with CAMSYNC_E_CAPACITY): what was obtained must still read
@@ -937,7 +976,6 @@ __global__ __launch_bounds__(64) void k_trace_decide(const uint32_t* __restrict_
         if (res >= 0) {
             active = false;
             if (accept && myOff != ~0u) {
-                const uint32_t planeIdx = (uint32_t)(c >> 40) * S + (uint32_t)((c >> 36) & 7u);
                 if (!bw) {
                     const uint32_t pos = (uint32_t)(c & 0xFFFFFFFFull);
                     ContourRec r;
@@ -950,22 +988,19 @@ __global__ __launch_bounds__(64) void k_trace_decide(const uint32_t* __restrict_
                     r.scanKey = pos + (isHole ? 1u : 0u);
                     contours[mySlot] = r;
                 }
+                // the steps of the last, partly filled word
+                if ((count & 7) != 0 && chChunk != ~0u) chain[(size_t)chChunk * 32 + (((count - 1) >> 3) & 31)] = chAcc;
+                // One copy task per piece.  The forward lane's pixels are points 0 .. count - 1 of the contour; the
+                // backward lane's pixel after m steps is point res - 1 - m (its states B_1 .. B_count are points
+                // res - 1 .. res - count).
                 for (unsigned int t = 0; t < nt; t++) {
-                    StoreTask k;
-                    k.plane = planeIdx;
-                    if (!bw) {
-                        // points [t*stride, min((t+1)*stride, count)) from the start or a checkpoint
-                        k.state = t == 0 ? state0 : myCk[t];
-                        k.dst = myOff + t * kCkStride;
-                        k.count = min((unsigned int)kCkStride, (unsigned int)count - t * kCkStride);
-                    } else {
-                        // the backward lane's states B_1..B_count are points res-1 ... res-count; piece t
-                        // starts at B_e, e = min((t+1)*stride, count), and runs forward for e - t*stride points
-                        const unsigned int e = min((t + 1) * (unsigned int)kCkStride, (unsigned int)count);
-                        k.state = e == (unsigned int)count ? prevState : myCk[t + 1];
-                        k.dst = myOff + (unsigned int)res - e;
-                        k.count = e - t * kCkStride;
-                    }
+                    const uint2 piece = myCk[t];
+                    const unsigned int np = min((unsigned int)kCkStride, (unsigned int)count - t * kCkStride);
+                    CopyTask k;
+                    k.chunk = piece.y;
+                    k.start = piece.x;
+                    k.dst = bw ? myOff + (unsigned int)res - 1u - t * kCkStride : myOff + t * kCkStride;
+                    k.n = np | (bw ? 0x80000000u : 0u);
                     tasks[myTask + t] = k;
                 }
             }
@@ -1064,6 +1099,54 @@ __global__ __launch_bounds__(64) void k_trace_store(const uint32_t* __restrict__
     }
 }
 
+// Write the points of the kept long borders: a half-wave per copy task.  Lane l of the half takes steps 8 l ..
+// 8 l + 7 of the piece's chain chunk; the pixel before step i is the piece's first pixel plus the sum of the
+// directions of steps 0 .. i - 1 (a prefix sum over the half-wave), and goes to dst + i or dst - i.
+__global__ __launch_bounds__(256) void k_trace_copy(const uint32_t* __restrict__ chain, const CopyTask* __restrict__ copies,
+                                                    unsigned int copyCap, unsigned int chainCap, uint32_t* __restrict__ pool,
+                                                    unsigned int poolCap, Counters* __restrict__ ctr) {
+    const unsigned int n = min(ctr->nCopy, copyCap);
+    const int lane = threadIdx.x & 63, l32 = lane & 31;
+    const unsigned int wave = blockIdx.x * 4u + (threadIdx.x >> 6), nWaves = gridDim.x * 4u;
+    for (unsigned int pair = wave; 2u * pair < n; pair += nWaves) {
+        const unsigned int t = 2u * pair + (unsigned int)(lane >> 5);
+        CopyTask k;
+        k.chunk = 0; k.start = 0; k.dst = 0; k.n = 0;
+        if (t < n) k = copies[t];
+        const unsigned int cnt = k.n & 0x7FFFFFFFu;
+        const bool rev = (k.n >> 31) != 0;
+        // (empty entries have n = 0; anything else out of range is not a task)
+        const bool good = cnt <= (unsigned int)kCkStride && k.chunk < chainCap && k.dst < poolCap &&
+                          (rev ? cnt <= k.dst + 1u : cnt <= poolCap - k.dst);
+        const uint32_t d = (good && (unsigned int)(8 * l32) < cnt) ? chain[(size_t)k.chunk * 32 + l32] : 0u;
+        int ox[8], oy[8], x = 0, y = 0;
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+            ox[m] = x;
+            oy[m] = y;
+            const int q = (int)((d >> (4 * m)) & 7u);
+            x += fast_dx(q);
+            y += fast_dy(q);
+        }
+        // inclusive prefix sums of the lanes' totals within the half-wave
+        int sx = x, sy = y;
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) {
+            const int tx = __shfl_up(sx, o, 32), ty = __shfl_up(sy, o, 32);
+            if (l32 >= o) {
+                sx += tx;
+                sy += ty;
+            }
+        }
+        const int bx = (int)(k.start & 0xFFFFu) + sx - x, by = (int)(k.start >> 16) + sy - y;
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+            const unsigned int i = (unsigned int)(8 * l32 + m);
+            if (good && i < cnt) pool[rev ? k.dst - i : k.dst + i] = (uint32_t)(bx + ox[m]) | ((uint32_t)(by + oy[m]) << 16);
+        }
+    }
+}
+
 }  // namespace
 
 void launch_contour_starts(const DetCfg& c, const DetBuffers& b, int B, hipStream_t st) {
@@ -1081,12 +1164,15 @@ void launch_trace(const DetCfg& c, const DetBuffers& b, hipStream_t st) {
     // (the start list is free after the short pass: it holds the tail records)
     TailRec* tail = reinterpret_cast<TailRec*>(b.cand);
     hipLaunchKernelGGL(k_trace_decide<false>, dim3(kTraceWaves), dim3(64), 0, st, b.planes, c, b.candLong, b.candCap, tail,
-                       b.contours, b.contourCap, b.poolCap, b.tasks, b.taskCap, b.ckpt, b.counters);
+                       b.contours, b.contourCap, b.poolCap, b.copies, b.copyCap, b.ckpt, b.chain, b.chainCap, b.counters);
     debug_stage(st, "trace_decide");
     hipLaunchKernelGGL(k_trace_decide<true>, dim3(kTraceWaves * kTailPairs * 2 / kTailLanes), dim3(64), 0, st, b.planes, c, b.candLong,
-                       b.candCap, tail, b.contours, b.contourCap, b.poolCap, b.tasks, b.taskCap, b.ckpt, b.counters);
+                       b.candCap, tail, b.contours, b.contourCap, b.poolCap, b.copies, b.copyCap, b.ckpt, b.chain, b.chainCap, b.counters);
     debug_stage(st, "trace_decide_tail");
-    hipLaunchKernelGGL(k_trace_store, dim3(kTraceWaves), dim3(64), 0, st, b.planes, c, b.tasks, b.taskCap, b.pool, b.poolCap, b.counters);
+    // points of the borders the short pass kept (followed once more from their start), then of the long ones
+    hipLaunchKernelGGL(k_trace_store, dim3(256 * 4), dim3(64), 0, st, b.planes, c, b.tasks, b.taskCap, b.pool, b.poolCap, b.counters);
+    debug_stage(st, "trace_store");
+    hipLaunchKernelGGL(k_trace_copy, dim3(256 * 8), dim3(256), 0, st, b.chain, b.copies, b.copyCap, b.chainCap, b.pool, b.poolCap, b.counters);
 }
 
 }  // namespace camsync
