@@ -770,6 +770,7 @@ __global__ __launch_bounds__(64) void k_trace_decide(const uint32_t* __restrict_
     uint2* myCk = ckpt + (size_t)ckSlot * kCkMax;
     // the directions of this lane's steps, eight to a word, go to chunks of kCkStride steps (see CopyTask)
     uint32_t chAcc = 0, chChunk = ~0u;
+    uint32_t* chWords = chain;  // the current chunk's 32 words
     bool chFail = false;
 
     bool active = false, exhausted = false, fresh = false, isHole = false;
@@ -803,6 +804,7 @@ __global__ __launch_bounds__(64) void k_trace_decide(const uint32_t* __restrict_
             ckSlot = r.ck;
             myCk = ckpt + (size_t)ckSlot * kCkMax;
             chChunk = r.chunk;
+            chWords = chain + (size_t)(chChunk == ~0u ? 0u : chChunk) * 32;
             chAcc = r.acc;
             chFail = r.fail != 0;
             active = true;
@@ -895,6 +897,7 @@ __global__ __launch_bounds__(64) void k_trace_decide(const uint32_t* __restrict_
                     chChunk = base == ~0u ? ~0u : base + (unsigned int)__popcll(bal & ((1ull << lane) - 1ull));
                     chFail = chFail || base == ~0u;
                     chAcc = 0;
+                    chWords = chain + (size_t)(chChunk == ~0u ? 0u : chChunk) * 32;
                     myCk[(count / kCkStride) & (kCkMax - 1)] = make_uint2((uint32_t)cx | ((uint32_t)cy << 16), chChunk);
                 }
             }
@@ -923,7 +926,7 @@ __global__ __launch_bounds__(64) void k_trace_decide(const uint32_t* __restrict_
             const uint32_t here = pack_state(cx, cy, bw ? q : s);
             chAcc |= (uint32_t)q << (4 * (count & 7));           // step `count` goes in direction q
             if ((count & 7) == 7) {
-                if (chChunk != ~0u) chain[(size_t)chChunk * 32 + ((count >> 3) & 31)] = chAcc;
+                if (chChunk != ~0u) chWords[(count >> 3) & 31] = chAcc;
                 chAcc = 0;
             }
             count++;
@@ -989,7 +992,7 @@ __global__ __launch_bounds__(64) void k_trace_decide(const uint32_t* __restrict_
                     contours[mySlot] = r;
                 }
                 // the steps of the last, partly filled word
-                if ((count & 7) != 0 && chChunk != ~0u) chain[(size_t)chChunk * 32 + (((count - 1) >> 3) & 31)] = chAcc;
+                if ((count & 7) != 0 && chChunk != ~0u) chWords[((count - 1) >> 3) & 31] = chAcc;
                 // One copy task per piece.  The forward lane's pixels are points 0 .. count - 1 of the contour; the
                 // backward lane's pixel after m steps is point res - 1 - m (its states B_1 .. B_count are points
                 // res - 1 .. res - count).
@@ -1105,6 +1108,7 @@ __global__ __launch_bounds__(64) void k_trace_store(const uint32_t* __restrict__
 __global__ __launch_bounds__(256) void k_trace_copy(const uint32_t* __restrict__ chain, const CopyTask* __restrict__ copies,
                                                     unsigned int copyCap, unsigned int chainCap, uint32_t* __restrict__ pool,
                                                     unsigned int poolCap, Counters* __restrict__ ctr) {
+    __shared__ uint32_t s_pts[8][256];  // per half-wave
     const unsigned int n = min(ctr->nCopy, copyCap);
     const int lane = threadIdx.x & 63, l32 = lane & 31;
     const unsigned int wave = blockIdx.x * 4u + (threadIdx.x >> 6), nWaves = gridDim.x * 4u;
@@ -1139,11 +1143,20 @@ __global__ __launch_bounds__(256) void k_trace_copy(const uint32_t* __restrict__
             }
         }
         const int bx = (int)(k.start & 0xFFFFu) + sx - x, by = (int)(k.start >> 16) + sy - y;
+        // through LDS, so that a store instruction writes 32 consecutive points instead of every eighth
+        uint32_t* const mine = s_pts[threadIdx.x >> 5];
+#pragma unroll
+        for (int m = 0; m < 8; m++) mine[(8 * l32 + m) ^ l32] = (uint32_t)(bx + ox[m]) | ((uint32_t)(by + oy[m]) << 16);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
         for (int m = 0; m < 8; m++) {
-            const unsigned int i = (unsigned int)(8 * l32 + m);
-            if (good && i < cnt) pool[rev ? k.dst - i : k.dst + i] = (uint32_t)(bx + ox[m]) | ((uint32_t)(by + oy[m]) << 16);
+            const unsigned int i = (unsigned int)(32 * m + l32);
+            const uint32_t v = mine[i ^ (i >> 3)];
+            if (good && i < cnt) pool[rev ? k.dst - i : k.dst + i] = v;
         }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
