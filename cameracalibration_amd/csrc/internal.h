@@ -99,7 +99,7 @@ struct CopyTask {
 };
 constexpr int kTraceWaves = 256 * 16;  // persistent single-wave workgroups of the long-border kernels
 constexpr int kCkStride = 256;         // a checkpoint (and a store task) every this many points
-constexpr int kTailPairs = 8;           // a decide wave with at most this many borders left hands them to the tail pass
+constexpr int kTailPairs = 16;          // a decide wave with at most this many borders left hands them to the tail pass
 constexpr int kCkMax = 32;             // checkpoints per direction: covers borders up to 2 * 32 * 256 points
 
 // Debugging aid (environment variable CAMSYNC_DEBUG_STAGES): wait for the stream after every kernel of the detection
