@@ -133,7 +133,7 @@ __device__ __forceinline__ void widen8(uint2 v, uint32_t o[4]) {
     o[3] = __builtin_amdgcn_perm(0u, v.y, 0x0C030C02u);
 }
 
-// a + / - one 16-bit half of w, and k times one byte of w: the sub-dword operand selects of the SDWA encoding
+// a + / - one 16-bit half of w: the sub-dword operand selects of the SDWA encoding
 // take the field straight out of the packed word, so the sums never have to be unpacked (that unpacking was a
 // quarter of this kernel's vector instructions).
 #define CAMSYNC_SDWA2(name, op, sel)                                                                              \
@@ -148,18 +148,6 @@ CAMSYNC_SDWA2(add_hi16, "v_add_u32_sdwa", "WORD_1")
 CAMSYNC_SDWA2(sub_lo16, "v_sub_u32_sdwa", "WORD_0")
 CAMSYNC_SDWA2(sub_hi16, "v_sub_u32_sdwa", "WORD_1")
 #undef CAMSYNC_SDWA2
-#define CAMSYNC_MULB(name, sel)                                                                                   \
-    __device__ __forceinline__ uint32_t name(uint32_t w, uint32_t k) {                                           \
-        uint32_t d;                                                                                               \
-        asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" sel " src1_sel:DWORD" \
-            : "=v"(d) : "v"(w), "v"(k));                                                                          \
-        return d;                                                                                                 \
-    }
-CAMSYNC_MULB(mul_b0, "BYTE_0")
-CAMSYNC_MULB(mul_b1, "BYTE_1")
-CAMSYNC_MULB(mul_b2, "BYTE_2")
-CAMSYNC_MULB(mul_b3, "BYTE_3")
-#undef CAMSYNC_MULB
 
 // value t of a row of packed words (value t = half t & 1 of word t >> 1)
 template <int T>
@@ -171,9 +159,9 @@ __device__ __forceinline__ uint32_t sub16(uint32_t a, const uint32_t* w) {
     return (T & 1) ? sub_hi16(a, w[T >> 1]) : sub_lo16(a, w[T >> 1]);
 }
 template <int LO, int R, int J>
-struct WinInit {  // a + sum of values LO - R .. LO - R + J - 1
+struct WinInit {  // a - sum of values LO - R .. LO - R + J - 1
     static __device__ __forceinline__ uint32_t run(uint32_t a, const uint32_t* w) {
-        return add16<LO - R + J - 1>(WinInit<LO, R, J - 1>::run(a, w), w);
+        return sub16<LO - R + J - 1>(WinInit<LO, R, J - 1>::run(a, w), w);
     }
 };
 template <int LO, int R>
@@ -184,7 +172,7 @@ template <int LO, int R, int I>
 struct WinSlide {  // out[I] from out[I - 1]
     static __device__ __forceinline__ void run(const uint32_t* w, uint32_t* out) {
         WinSlide<LO, R, I - 1>::run(w, out);
-        out[I] = sub16<LO + I - 1 - R>(add16<LO + I + R>(out[I - 1], w), w);
+        out[I] = add16<LO + I - 1 - R>(sub16<LO + I + R>(out[I - 1], w), w);
     }
 };
 template <int LO, int R>
@@ -192,8 +180,8 @@ struct WinSlide<LO, R, 0> {
     static __device__ __forceinline__ void run(const uint32_t*, uint32_t*) {}
 };
 
-// Sliding horizontal sum of radius R over the exchanged vertical sums, starting from `init` (the caller folds
-// the threshold's constant in there).
+// `init` MINUS the sliding horizontal sum of radius R over the exchanged vertical sums (the caller folds the
+// threshold's constant into init; negated, so that the comparison below is one multiply-add).
 // The exchange buffer of one scale is laid out by word: word j (two sums) of every lane is contiguous,
 // xb[j * XROW + XPAD + lane], so that whichever word offset a lane reads from its neighbours, the 64 lanes
 // of the instruction touch 64 consecutive words (no bank conflicts; a 16-byte lane stride read 4 bytes at a
@@ -215,20 +203,14 @@ __device__ __forceinline__ void hsum8(const uint32_t* xb, int lane, uint32_t ini
     WinSlide<LO, R, 7>::run(w, out);
 }
 
-// bit i of the result = (s[i] > K c[i]) as signed numbers (the caller starts s from 1 minus the threshold's
-// constant, which makes this the >= of the definition).  K c - s is negative exactly then, and a funnel shift
-// appends its sign bit to the byte under construction: multiply, subtract, shift per pixel, no condition codes
-// (a compare feeding a select costs wait states on this chip).  c = the 8 centre bytes, k = K in a register.
-__device__ __forceinline__ uint32_t thresh_bits(const uint32_t s[8], uint2 c, uint32_t k) {
+// bit i of the result = (K c[i] + t[i] < 0), t = (the threshold's constant - 1) - window sum: the >= of the
+// definition.  A funnel shift appends the sign bit to the byte under construction: multiply-add and shift per
+// pixel, no condition codes (a compare feeding a select costs wait states on this chip).  c = the 8 centre
+// values, k = K.
+__device__ __forceinline__ uint32_t thresh_bits(const uint32_t t[8], const uint32_t c[8], uint32_t k) {
     uint32_t acc = 0;
-    acc = __builtin_amdgcn_alignbit(acc, mul_b3(c.y, k) - s[7], 31);
-    acc = __builtin_amdgcn_alignbit(acc, mul_b2(c.y, k) - s[6], 31);
-    acc = __builtin_amdgcn_alignbit(acc, mul_b1(c.y, k) - s[5], 31);
-    acc = __builtin_amdgcn_alignbit(acc, mul_b0(c.y, k) - s[4], 31);
-    acc = __builtin_amdgcn_alignbit(acc, mul_b3(c.x, k) - s[3], 31);
-    acc = __builtin_amdgcn_alignbit(acc, mul_b2(c.x, k) - s[2], 31);
-    acc = __builtin_amdgcn_alignbit(acc, mul_b1(c.x, k) - s[1], 31);
-    acc = __builtin_amdgcn_alignbit(acc, mul_b0(c.x, k) - s[0], 31);
+#pragma unroll
+    for (int i = 7; i >= 0; i--) acc = __builtin_amdgcn_alignbit(acc, __umul24(c[i], k) + t[i], 31);
     return acc;
 }
 
@@ -262,9 +244,6 @@ __global__ __launch_bounds__(TPB) void k_gray_thresh3(const uint8_t* __restrict_
     const bool inOut = (tid >= HALO / PX) && (tid < TPB - HALO / PX) && xbase < W;  // produces output
     const bool fullOut = inOut && (xbase + 7 < W) && aligned;
     constexpr int K0 = (2 * R0 + 1) * (2 * R0 + 1), K1 = (2 * R1 + 1) * (2 * R1 + 1), K2 = (2 * R2 + 1) * (2 * R2 + 1);
-    // (the window areas live in vector registers: the SDWA multiply takes no literal)
-    uint32_t kk0 = K0, kk1 = K1, kk2 = K2;
-    asm volatile("" : "+v"(kk0), "+v"(kk1), "+v"(kk2));
     const int c0 = ((2 * idelta - 1) * K0 + 1) >> 1, c1 = ((2 * idelta - 1) * K1 + 1) >> 1, c2 = ((2 * idelta - 1) * K2 + 1) >> 1;
 
     // vertical running sums, two 16-bit fields per word (at most 23 * 255 per field)
@@ -371,11 +350,13 @@ __global__ __launch_bounds__(TPB) void k_gray_thresh3(const uint8_t* __restrict_
 
         if (inOut) {
             uint32_t s0[8], s1[8], s2[8];
-            hsum8<R0>(xbuf[0], tid, (uint32_t)(1 - c0), s0);
-            hsum8<R1>(xbuf[1], tid, (uint32_t)(1 - c1), s1);
-            hsum8<R2>(xbuf[2], tid, (uint32_t)(1 - c2), s2);
+            hsum8<R0>(xbuf[0], tid, (uint32_t)(c0 - 1), s0);
+            hsum8<R1>(xbuf[1], tid, (uint32_t)(c1 - 1), s1);
+            hsum8<R2>(xbuf[2], tid, (uint32_t)(c2 - 1), s2);
+            uint32_t cv[8];
+            unpack8(cen, cv);
             // one byte per scale, bit i = pixel xbase+i
-            const uint32_t pm0 = thresh_bits(s0, cen, kk0), pm1 = thresh_bits(s1, cen, kk1), pm2 = thresh_bits(s2, cen, kk2);
+            const uint32_t pm0 = thresh_bits(s0, cv, K0), pm1 = thresh_bits(s1, cv, K1), pm2 = thresh_bits(s2, cv, K2);
             const size_t off = frameOff + (size_t)y * W + xbase;
             if (fullOut) {
                 if (bin) {
