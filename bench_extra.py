@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
 """Secondary measurements of SURVEY.md §8(d) that are not the bench line (bench.py prints that one):
 
-  * configs[2] on one GPU: detection of 3840x2160 frames with 40 markers each (frames/s, resident input);
+  * configs[2] on one GPU: detection of 3840x2160 frames with 40 markers each (frames/s, resident input; only with
+    --frames4k N);
   * config 5: wall latency of `processArucoFromMultipleCameras` for 8 cameras looking at one scene
-    (p50 / p99 over repeated frame-sets, 1280x720 and 1920x1080), host frames in, Python mirror API;
-  * the PCIe-inclusive rate of the host-buffer entry point.
+    (p50 / p99 over repeated frame-sets, 1280x720 and 1920x1080), host frames in, Python mirror API,
+    and the same eight 1080p frames as one batch (processArucoBatch).
 
     python bench_extra.py [--frames4k 256] [--sets 200] > profiles/rNN_extra.json
 

@@ -751,7 +751,7 @@ static_assert(sizeof(TailRec) == 40, "tail records are sized against the start l
 // following one or two very long borders with 60 idle lanes, all of them competing for issue slots.  A wave
 // whose queue is empty and that has at most kTailPairs borders left therefore writes their state to the tail
 // list and exits; the RESUME instance packs those borders 32 to a wave and finishes them.
-constexpr int kTailLanes = 64;  // borders (x2) per wave of the tail pass: few, so that window moves are rare
+constexpr int kTailLanes = 64;  // lanes (two per border) a wave of the tail pass takes over (fewer per wave was slower)
 template <bool RESUME>
 __global__ __launch_bounds__(64) void k_trace_decide(const uint32_t* __restrict__ planes, DetCfg cfg,
                                                      const uint64_t* __restrict__ candLong, unsigned int candCap,
@@ -1172,7 +1172,7 @@ void launch_contour_starts(const DetCfg& c, const DetBuffers& b, int B, hipStrea
 void launch_trace(const DetCfg& c, const DetBuffers& b, hipStream_t st) {
     hipLaunchKernelGGL(k_trace_short, dim3(256 * 8), dim3(256), 0, st, b.planes, c, b.cand, b.candCap, b.candLong,
                        b.contours, b.contourCap, b.poolCap, b.tasks, b.taskCap, b.counters);
-    // persistent: 10 single-wave workgroups per CU (16 KiB of LDS each)
+    // the long-border kernels are persistent: 16 single-wave workgroups per CU (8 KiB of LDS each)
     debug_stage(st, "trace_short");
     // (the start list is free after the short pass: it holds the tail records)
     TailRec* tail = reinterpret_cast<TailRec*>(b.cand);
