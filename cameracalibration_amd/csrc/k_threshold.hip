@@ -143,42 +143,62 @@ __device__ __forceinline__ void widen8(uint2 v, uint32_t o[4]) {
             : "=v"(d) : "v"(a), "v"(w));                                                                          \
         return d;                                                                                                 \
     }
-CAMSYNC_SDWA2(add_lo16, "v_add_u32_sdwa", "WORD_0")
-CAMSYNC_SDWA2(add_hi16, "v_add_u32_sdwa", "WORD_1")
 CAMSYNC_SDWA2(sub_lo16, "v_sub_u32_sdwa", "WORD_0")
 CAMSYNC_SDWA2(sub_hi16, "v_sub_u32_sdwa", "WORD_1")
 #undef CAMSYNC_SDWA2
 
-// value t of a row of packed words (value t = half t & 1 of word t >> 1)
-template <int T>
-__device__ __forceinline__ uint32_t add16(uint32_t a, const uint32_t* w) {
-    return (T & 1) ? add_hi16(a, w[T >> 1]) : add_lo16(a, w[T >> 1]);
-}
-template <int T>
-__device__ __forceinline__ uint32_t sub16(uint32_t a, const uint32_t* w) {
-    return (T & 1) ? sub_hi16(a, w[T >> 1]) : sub_lo16(a, w[T >> 1]);
-}
-template <int LO, int R, int J>
-struct WinInit {  // a - sum of values LO - R .. LO - R + J - 1
-    static __device__ __forceinline__ uint32_t run(uint32_t a, const uint32_t* w) {
-        return sub16<LO - R + J - 1>(WinInit<LO, R, J - 1>::run(a, w), w);
-    }
-};
+// a - (sum of values LO - R .. LO + R): the whole words are added as packed pairs first (a field holds at most
+// (2R+1) 255, so the pair sums of up to 11 words stay below 2^16), then the two halves of that sum and the
+// single values at either end come off a.
 template <int LO, int R>
-struct WinInit<LO, R, 0> {
-    static __device__ __forceinline__ uint32_t run(uint32_t a, const uint32_t*) { return a; }
-};
-template <int LO, int R, int I>
-struct WinSlide {  // out[I] from out[I - 1]
-    static __device__ __forceinline__ void run(const uint32_t* w, uint32_t* out) {
-        WinSlide<LO, R, I - 1>::run(w, out);
-        out[I] = add16<LO + I - 1 - R>(sub16<LO + I + R>(out[I - 1], w), w);
-    }
-};
+__device__ __forceinline__ uint32_t win_init(uint32_t a, const uint32_t* w) {
+    constexpr int F0 = LO - R, F1 = LO + R;                 // first and last value
+    constexpr int W0 = (F0 + 1) >> 1, W1 = (F1 - 1) >> 1;  // whole words
+    static_assert(F0 >= 0 && W1 >= W0, "window must cover at least one whole word");
+    static_assert((W1 - W0 + 1) * (2 * R + 1) * 255 < 65536, "packed partial sums must fit 16 bits");
+    uint32_t p = w[W0];
+#pragma unroll
+    for (int i = W0 + 1; i <= W1; i++) p += w[i];
+    uint32_t d;
+    asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n\t"
+        "v_sub_u32_sdwa %0, %0, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1"
+        : "=&v"(d) : "v"(a), "v"(p));
+    if (F0 & 1) d = sub_hi16(d, w[F0 >> 1]);
+    if (!(F1 & 1)) d = sub_lo16(d, w[F1 >> 1]);
+    return d;
+}
+
+// out[1 .. 7] from out[0]: out[I] = out[I - 1] - value(LO + I + R) + value(LO + I - 1 - R).  One asm block: the
+// compiler cannot see into asm statements and separates dependent ones by a wait state that these (full-dword
+// destinations) do not need; that was 60 s_nop per row.  LO is even, so the halves alternate with I and start
+// according to the parity of R.
+#define CAMSYNC_SLIDE(o, p, n, q, sn, so)                                                                        \
+    "v_sub_u32_sdwa %" #o ", %" #p ", %" #n " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:" sn "\n\t" \
+    "v_add_u32_sdwa %" #o ", %" #o ", %" #q " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:" so "\n\t"
+#define CAMSYNC_SLIDE7(sa, sb)                                                                                   \
+    CAMSYNC_SLIDE(0, 7, 8, 15, sa, sb) CAMSYNC_SLIDE(1, 0, 9, 16, sb, sa) CAMSYNC_SLIDE(2, 1, 10, 17, sa, sb)      \
+    CAMSYNC_SLIDE(3, 2, 11, 18, sb, sa) CAMSYNC_SLIDE(4, 3, 12, 19, sa, sb) CAMSYNC_SLIDE(5, 4, 13, 20, sb, sa)    \
+    CAMSYNC_SLIDE(6, 5, 14, 21, sa, sb)
 template <int LO, int R>
-struct WinSlide<LO, R, 0> {
-    static __device__ __forceinline__ void run(const uint32_t*, uint32_t*) {}
-};
+__device__ __forceinline__ void win_slide7(const uint32_t* w, uint32_t* out) {
+    static_assert((LO & 1) == 0, "LO must be even");
+#define CAMSYNC_NW(I) "v"(w[(LO + (I) + R) >> 1])
+#define CAMSYNC_OW(I) "v"(w[(LO + (I) - 1 - R) >> 1])
+#define CAMSYNC_SLIDE_OPS                                                                                         \
+    : "=&v"(out[1]), "=&v"(out[2]), "=&v"(out[3]), "=&v"(out[4]), "=&v"(out[5]), "=&v"(out[6]), "=&v"(out[7])    \
+    : "v"(out[0]), CAMSYNC_NW(1), CAMSYNC_NW(2), CAMSYNC_NW(3), CAMSYNC_NW(4), CAMSYNC_NW(5), CAMSYNC_NW(6),      \
+      CAMSYNC_NW(7), CAMSYNC_OW(1), CAMSYNC_OW(2), CAMSYNC_OW(3), CAMSYNC_OW(4), CAMSYNC_OW(5), CAMSYNC_OW(6),    \
+      CAMSYNC_OW(7)
+    if (R & 1)  // I odd: the new value is an even one (low half), the old one odd
+        asm(CAMSYNC_SLIDE7("WORD_0", "WORD_1") CAMSYNC_SLIDE_OPS);
+    else
+        asm(CAMSYNC_SLIDE7("WORD_1", "WORD_0") CAMSYNC_SLIDE_OPS);
+#undef CAMSYNC_SLIDE_OPS
+#undef CAMSYNC_OW
+#undef CAMSYNC_NW
+}
+#undef CAMSYNC_SLIDE7
+#undef CAMSYNC_SLIDE
 
 // `init` MINUS the sliding horizontal sum of radius R over the exchanged vertical sums (the caller folds the
 // threshold's constant into init; negated, so that the comparison below is one multiply-add).
@@ -199,8 +219,8 @@ __device__ __forceinline__ void hsum8(const uint32_t* xb, int lane, uint32_t ini
         const int d = i - LO / 2;  // word offset from the lane's first word: lane + (d >> 2), word d & 3
         w[i] = xb[(d & 3) * XROW + XPAD + lane + (d >> 2)];
     }
-    out[0] = WinInit<LO, R, 2 * R + 1>::run(init, w);
-    WinSlide<LO, R, 7>::run(w, out);
+    out[0] = win_init<LO, R>(init, w);
+    win_slide7<LO, R>(w, out);
 }
 
 // bit i of the result = (K c[i] + t[i] < 0), t = (the threshold's constant - 1) - window sum: the >= of the
