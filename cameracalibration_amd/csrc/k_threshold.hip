@@ -239,7 +239,7 @@ __device__ __forceinline__ uint32_t thresh_bits(const uint32_t t[8], const uint3
 // can track across rows; MODE 0 takes them at run time.
 template <int R0, int R1, int R2, int MODE>
 __global__ __launch_bounds__(TPB) void k_gray_thresh3(const uint8_t* __restrict__ in, int C_, uint8_t* __restrict__ gray,
-                                                      uint8_t* __restrict__ bin_, uint32_t* __restrict__ planes, int WS, int H, int W, int bandH, int idelta) {
+                                                      uint8_t* __restrict__ bin_, uint32_t* __restrict__ planes, int WS, int H, int W, int bandH, int idelta, int nFrames) {
     const int C = MODE == 1 ? 3 : MODE == 2 ? 1 : C_;
     uint8_t* const bin = MODE ? nullptr : bin_;
     const bool hasGray = MODE ? true : gray != nullptr;
@@ -250,14 +250,25 @@ __global__ __launch_bounds__(TPB) void k_gray_thresh3(const uint8_t* __restrict_
     __shared__ uint32_t xbuf[3][4 * XROW];  // vertical sums of one row, by word (hsum8)
     // STG rows of plane bits of this strip, laid out like the planes (scale, block, row): flushed as 16-byte pieces
     constexpr int NBLK = CHUNKW / 32;
-    constexpr int STG = 8;  // rows staged per flush (four: flushing costs more than the sixteenth wave per CU gains)
+    // rows staged per flush: 16 rows of a block are 64 bytes, the unit memory is written in (8 rows: 32-byte pieces
+    // that the L2 has evicted before the block's next piece arrives, +0.9 ms; 32 rows: too much LDS)
+    constexpr int STG = 16;
     __shared__ __align__(16) uint32_t stage[3][NBLK][STG];
 
     const int tid = threadIdx.x;
-    const int f = blockIdx.z;
-    const int y0 = blockIdx.y * bandH;
+    // 1-D grid; workgroups 8 apart share an XCD (its L2), and the strips of one band of one frame are made such
+    // workgroups: the cache lines of the gray rows that two neighbouring strips both write parts of meet in one L2,
+    // and so do the halo columns both read.  Workgroup = (group of 8 units, strip, unit in the group), unit = band
+    // of a frame.
+    const int nStrips = (W + CHUNKW - 1) / CHUNKW, nBands = (H + bandH - 1) / bandH;
+    const int grp = blockIdx.x / (8 * nStrips), rem = blockIdx.x - grp * (8 * nStrips);
+    const int unit = grp * 8 + (rem & 7);
+    if (unit >= nBands * nFrames) return;
+    const int f = unit / nBands;
+    const int y0 = (unit - f * nBands) * bandH;
+    const int stripIdx = rem >> 3;
     const int y1 = min(H, y0 + bandH);
-    const int cx0 = blockIdx.x * CHUNKW;
+    const int cx0 = stripIdx * CHUNKW;
     const int xbase = cx0 - HALO + PX * tid;
     const bool aligned = MODE ? true : (W % 8) == 0;
     const size_t frameOff = (size_t)f * H * W;
@@ -498,11 +509,11 @@ void launch_gray_thresh(const DetCfg& c, const DetBuffers& b, int B, int C, hipS
     const bool fast = c.nScales == 3 && c.radius[0] == 1 && c.radius[1] == 6 && c.radius[2] == 11;
     if (fast) {
         const int chunks = (c.W + CHUNKW - 1) / CHUNKW;
-        // Single-wave workgroups of equal length, 15 resident per CU (LDS): the launch runs in rounds, and a last
+        // Single-wave workgroups of equal length, 12 resident per CU (registers): the launch runs in rounds, and a last
         // round that is mostly empty costs as much as a full one.  Choose the number of bands per strip that
         // minimises rounds x band length; every band re-reads 2 rmax + 2 rows above it to warm its running sums
         // up (about 12 rows' worth of time), and bands are whole plane blocks.
-        const long slots = 256L * 15;
+        const long slots = 256L * 12;
         const int maxBands = max(1, (c.H + 63) / 64);
         int bands = 1, bandH = (c.H + 31) & ~31;
         long best = -1;
@@ -517,14 +528,15 @@ void launch_gray_thresh(const DetCfg& c, const DetBuffers& b, int B, int C, hipS
                 bandH = bh;
             }
         }
-        dim3 grid(chunks, bands, B);
+        // 1-D grid, see the kernel: groups of 8 units x strips
+        dim3 grid((unsigned)(((long)bands * B + 7) / 8 * 8 * chunks));
         const bool plain = (c.W % 8) == 0 && !b.bin && b.gray;
         if (plain && C == 3)
-            hipLaunchKernelGGL((k_gray_thresh3<1, 6, 11, 1>), grid, dim3(TPB), 0, st, b.in, C, b.gray, b.bin, b.planes, c.WS, c.H, c.W, bandH, c.idelta);
+            hipLaunchKernelGGL((k_gray_thresh3<1, 6, 11, 1>), grid, dim3(TPB), 0, st, b.in, C, b.gray, b.bin, b.planes, c.WS, c.H, c.W, bandH, c.idelta, B);
         else if (plain && C == 1)
-            hipLaunchKernelGGL((k_gray_thresh3<1, 6, 11, 2>), grid, dim3(TPB), 0, st, b.in, C, b.gray, b.bin, b.planes, c.WS, c.H, c.W, bandH, c.idelta);
+            hipLaunchKernelGGL((k_gray_thresh3<1, 6, 11, 2>), grid, dim3(TPB), 0, st, b.in, C, b.gray, b.bin, b.planes, c.WS, c.H, c.W, bandH, c.idelta, B);
         else
-            hipLaunchKernelGGL((k_gray_thresh3<1, 6, 11, 0>), grid, dim3(TPB), 0, st, b.in, C, b.gray, b.bin, b.planes, c.WS, c.H, c.W, bandH, c.idelta);
+            hipLaunchKernelGGL((k_gray_thresh3<1, 6, 11, 0>), grid, dim3(TPB), 0, st, b.in, C, b.gray, b.bin, b.planes, c.WS, c.H, c.W, bandH, c.idelta, B);
     } else {
         size_t total = (size_t)B * c.H * c.W;
         unsigned blocks = (unsigned)((total + 255) / 256);

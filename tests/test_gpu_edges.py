@@ -121,6 +121,42 @@ def test_4k_forty_markers_config():
     assert n >= 24 and set(ids[0, :n].tolist()) <= want
 
 
+def test_resident_batch_beyond_4gb_equals_host_calls():
+    """`camsync_detect_pnp_resident` (the bench's entry point) on 720 resident 1080p frames = 4.5 GB of input,
+    8 distinct frames repeated: every frame's ids, corners and pose must equal what the host-buffer entry point
+    gives for that frame alone, wherever the frame lies (byte offsets beyond 2^31 and 2^32 included)."""
+    import torch
+    K, dist = _data.calibration("Logitec_robot_1920-1080_10.npz")
+    H, W, B, MM = 1080, 1920, 720, 16
+    base = np.stack([synth.v1_frame(40 + i, K, ss=2)[0].numpy() for i in range(8)])
+    anchors = [10, 11, 14, 15]
+    obj = _data.v1_anchor_points(anchors)
+    ctx = _hip.Context(H, W, max_batch=B)
+    ids0, cor0, cnt0, rv0, tv0, ok0, _, _ = ctx.detect_pnp(base, anchors, obj, K, dist, max_markers=MM)
+    assert (cnt0 >= 5).all() and (ok0 == 1).all()
+    dev = torch.device("cuda", 0)
+    frames = torch.from_numpy(base).to(dev).repeat(B // 8, 1, 1, 1).contiguous()
+    assert frames.numel() > (1 << 32)
+    d_ids = torch.full((B, MM), -1, dtype=torch.int32, device=dev)
+    d_cor = torch.zeros((B, MM, 4, 2), dtype=torch.float32, device=dev)
+    d_cnt = torch.zeros((B,), dtype=torch.int32, device=dev)
+    d_rv = torch.zeros((B, 3), dtype=torch.float64, device=dev)
+    d_tv = torch.zeros((B, 3), dtype=torch.float64, device=dev)
+    d_ok = torch.zeros((B,), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    ctx.detect_pnp_resident(frames.data_ptr(), B, H, W, 3, anchors, obj, K, dist, MM, d_ids.data_ptr(), d_cor.data_ptr(),
+                            d_cnt.data_ptr(), d_rv.data_ptr(), d_tv.data_ptr(), d_ok.data_ptr())
+    torch.cuda.synchronize()
+    rep = B // 8
+    assert np.array_equal(d_cnt.cpu().numpy(), np.tile(cnt0, rep))
+    used = np.arange(MM)[None, :] < np.tile(cnt0, rep)[:, None]  # entries beyond a frame's count are unspecified
+    assert np.array_equal(d_ids.cpu().numpy()[used], np.tile(ids0, (rep, 1))[used])
+    assert np.array_equal(d_cor.cpu().numpy()[used], np.tile(cor0, (rep, 1, 1, 1))[used])
+    assert np.array_equal(d_ok.cpu().numpy(), np.tile(ok0, rep))
+    assert np.array_equal(d_rv.cpu().numpy(), np.tile(rv0, (rep, 1)))
+    assert np.array_equal(d_tv.cpu().numpy(), np.tile(tv0, (rep, 1)))
+
+
 def test_argument_errors_and_limits():
     ctx = _hip.Context(64, 64, 1)
     with pytest.raises(_hip.CamsyncError):
