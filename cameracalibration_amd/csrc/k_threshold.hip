@@ -15,6 +15,11 @@
 // fetched from HBM once (plus the strip halos) and the three threshold images
 // leave as bit planes (one bit per pixel and scale).
 //
+// What bounds it (measured by taking parts out, profiles/r01_notes.md): memory, and within memory the writes.
+// With all arithmetic removed the kernel takes as long as with it; the 1.4 B/px it writes cost as much time as
+// the 3.4 B/px it reads.  Hence the strips of one band are placed on one XCD (the cache lines that two strips
+// write parts of, and the halo columns both read, meet in one L2) and the plane bits leave in 64-byte pieces.
+//
 // Integer-exact: luma = (3735 B + 19235 G + 9798 R + 2^14) >> 15;
 // out_s = 1  <=>  round(sum/k^2) >= src + idelta  <=>  2 sum >= (2(src+idelta)-1) k^2
 //            <=>  sum >= k^2 src + ((2 idelta - 1) k^2 + 1) / 2
