@@ -42,15 +42,13 @@ namespace camsync {
 
 namespace {
 
-// fill `seed` along runs of `run` towards lower bit positions (Kogge-Stone)
+// fill `seed` along runs of `run` towards lower bit positions.  Bit-reversed, "towards lower" is the direction
+// carries travel: adding the seeds to the runs clears each run from its lowest seed up to its end (the carry lands
+// on the zero after the run, and later seeds of the same run fall on cleared bits), so the bits the addition
+// changed, within the runs, plus the seeds, are the filled runs.  8 instructions instead of the 25 of a Kogge-Stone fill.
 __device__ __forceinline__ uint32_t fill_down(uint32_t seed, uint32_t run) {
-    uint32_t f = seed & run, m = run;
-    f |= (f >> 1) & m; m &= m >> 1;
-    f |= (f >> 2) & m; m &= m >> 2;
-    f |= (f >> 4) & m; m &= m >> 4;
-    f |= (f >> 8) & m; m &= m >> 8;
-    f |= (f >> 16) & m;
-    return f;
+    const uint32_t r = __brev(run), s = __brev(seed) & r;
+    return __brev((((r + s) ^ r) & r) | s);
 }
 
 constexpr int kStage = 512;  // starts staged per wavefront before a flush
