@@ -20,6 +20,11 @@ namespace {
 
 constexpr int kMaxWin = 20;
 constexpr int kMaxPatch = 2 * kMaxWin + 3;
+// The corner moves by a fraction of a pixel per iteration, so the pixels every iteration's patch needs are almost
+// always those of the first patch and a few around them: that region is copied to LDS once per corner and the
+// patches are sampled from there (same bytes, same arithmetic); a patch that leaves it is sampled from the image.
+constexpr int kRegMargin = 4;
+constexpr int kRegDim = kMaxPatch + 1 + 2 * kRegMargin;
 
 __device__ __forceinline__ double wave_sum_d(double v) {
     return wave_allreduce(v, [](double a, double b) { return a + b; });
@@ -70,19 +75,21 @@ __device__ __forceinline__ PatchGeom patch_geom(float cx, float cy, int pw, int 
     return g;
 }
 
-__device__ __forceinline__ float patch_elem(const uint8_t* __restrict__ src, int W, int H, const PatchGeom& g, int i, int j) {
-    if (g.fast) {
-        const uint8_t* p = src + (size_t)(g.ipy + i) * W + g.ipx;
-        const float t = g.a12 * p[j + 1] + g.a22 * p[j + 1 + W];
-        float prev;
-        if (j == 0) {
-            prev = (1 - g.a) * (g.b1 * p[0] + g.b2 * p[W]);
-        } else {
-            const float tp = g.a12 * p[j] + g.a22 * p[j + W];
-            prev = (float)(tp * g.s);
-        }
-        return prev + t;
+// the patch lies inside the image: p = first pixel of patch row i, stride = bytes per image row
+__device__ __forceinline__ float patch_elem_inside(const uint8_t* __restrict__ p, int stride, const PatchGeom& g, int j) {
+    const float t = g.a12 * p[j + 1] + g.a22 * p[j + 1 + stride];
+    float prev;
+    if (j == 0) {
+        prev = (1 - g.a) * (g.b1 * p[0] + g.b2 * p[stride]);
+    } else {
+        const float tp = g.a12 * p[j] + g.a22 * p[j + stride];
+        prev = (float)(tp * g.s);
     }
+    return prev + t;
+}
+
+__device__ __forceinline__ float patch_elem(const uint8_t* __restrict__ src, int W, int H, const PatchGeom& g, int i, int j) {
+    if (g.fast) return patch_elem_inside(src + (size_t)(g.ipy + i) * W + g.ipx, W, g, j);
     const int y0 = min(max(g.ipy + i, 0), H - 1), y1 = min(max(g.ipy + i + 1, 0), H - 1);
     const uint8_t* r0 = src + (size_t)y0 * W;
     const uint8_t* r1 = src + (size_t)y1 * W;
@@ -97,6 +104,7 @@ __global__ __launch_bounds__(64) void k_subpix(const uint8_t* __restrict__ gray,
                                                const float* __restrict__ rawCorners, float* __restrict__ outCorners,
                                                const float* __restrict__ expTab, DetCfg cfg) {
     __shared__ float s_buf[kMaxPatch * kMaxPatch];
+    __shared__ uint8_t s_reg[kRegDim * kRegDim];
     const int lane = threadIdx.x;
     const unsigned int nM = min(ctr->nMarkers, markerCap);
     const int H = cfg.H, W = cfg.W;
@@ -129,15 +137,41 @@ __global__ __launch_bounds__(64) void k_subpix(const uint8_t* __restrict__ gray,
         float cIx = cTx, cIy = cTy;
         int iter = 0;
         double err = 0;
+        // the region around the first patch, clipped to the image
+        const PatchGeom g0 = patch_geom(cIx, cIy, pw, W, H);
+        const int rx0 = max(g0.ipx - kRegMargin, 0), ry0 = max(g0.ipy - kRegMargin, 0);
+        const int rx1 = min(g0.ipx + pw + kRegMargin, W - 1), ry1 = min(g0.ipy + pw + kRegMargin, H - 1);
+        const int rw = rx1 - rx0 + 1, rh = ry1 - ry0 + 1;
+        const bool hasReg = rw > 0 && rh > 0 && rw <= kRegDim && rh <= kRegDim;
+        __syncthreads();
+        if (hasReg) {
+            const int qi = 64 / rw, qj = 64 - qi * rw;
+            for (int e = lane, i = lane / rw, j = lane - (lane / rw) * rw; e < rw * rh; e += 64) {
+                s_reg[e] = src[(size_t)(ry0 + i) * W + rx0 + j];
+                i += qi;
+                j += qj;
+                if (j >= rw) { j -= rw; i++; }
+            }
+        }
         do {
             const PatchGeom g = patch_geom(cIx, cIy, pw, W, H);
             __syncthreads();
             // element e = lane + 64 k of the patch is (row, column) = (i, j); stepping by 64 elements without dividing
-            for (int e = lane, i = pi0, j = pj0; e < pw * pw; e += 64) {
-                s_buf[e] = patch_elem(src, W, H, g, i, j);
-                i += pqi;
-                j += pqj;
-                if (j >= pw) { j -= pw; i++; }
+            if (hasReg && g.fast && g.ipx >= rx0 && g.ipx + pw <= rx1 && g.ipy >= ry0 && g.ipy + pw <= ry1) {
+                const uint8_t* rp = s_reg + (g.ipy - ry0) * rw + (g.ipx - rx0);
+                for (int e = lane, i = pi0, j = pj0; e < pw * pw; e += 64) {
+                    s_buf[e] = patch_elem_inside(rp + i * rw, rw, g, j);
+                    i += pqi;
+                    j += pqj;
+                    if (j >= pw) { j -= pw; i++; }
+                }
+            } else {
+                for (int e = lane, i = pi0, j = pj0; e < pw * pw; e += 64) {
+                    s_buf[e] = patch_elem(src, W, H, g, i, j);
+                    i += pqi;
+                    j += pqj;
+                    if (j >= pw) { j -= pw; i++; }
+                }
             }
             __syncthreads();
             double a = 0, b = 0, c = 0, bb1 = 0, bb2 = 0;
