@@ -196,6 +196,14 @@ int enqueue_detect(camsync_ctx* c, const uint8_t* d_in, int B, int H, int W, int
     DetBuffers b = c->buf;
     b.in = d_in;
     b.bin = nullptr;
+    if (gray_thresh_is_fused(cfg)) {  // no gray image: K6 and K7 read the input frame (GraySrc)
+        b.gray = nullptr;
+        b.graySrc = d_in;
+        b.graySrcC = C;
+    } else {
+        b.graySrc = b.gray;
+        b.graySrcC = 1;
+    }
     HIPCHK(c, hipMemsetAsync(b.counters, 0, sizeof(Counters), c->stream));
     HIPCHK(c, hipMemsetAsync(b.qcount, 0, sizeof(int) * B, c->stream));
     StageTimer t(c);

@@ -132,9 +132,40 @@ struct Counters {
     unsigned int pad;
 };
 
+// The detection pipeline does not write the gray image when the fused K1+K2 kernel runs: it is a fifth of that
+// kernel's memory traffic and more of its time, and only K6 (marker bits) and K7 (sub-pixel corners) look at gray
+// values again, a few thousand per marker.  They convert them from the input frame as they read them, with K1's
+// integer luma (cv.cvtColor BGR2GRAY: (3735 B + 19235 G + 9798 R + 2^14) >> 15).
+struct GraySrc {
+    const uint8_t* p;  // first byte of the frame
+    int C;             // bytes per pixel: 1 = gray values, 3 = BGR
+    uint32_t last;     // index of the frame's last pixel
+#ifdef __HIPCC__
+    __device__ __forceinline__ int at(size_t idx) const {
+        if (C == 1) return p[idx];
+        const uint8_t* q = p + idx * 3;
+        uint32_t bgr;  // B | G << 8 | R << 16
+        if (idx < last) {
+            // one (unaligned) 4-byte load; its fourth byte belongs to the next pixel of the frame
+            uint32_t w;
+            __builtin_memcpy(&w, q, 4);
+            bgr = w & 0x00FFFFFFu;
+        } else {
+            bgr = q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16);
+        }
+        // the weights split as w = 256 wh + wl, each half a byte dot product (as in K1)
+        const uint32_t lo = __builtin_amdgcn_udot4(bgr, 0x00462397u, 16384u, false);
+        const uint32_t hi = __builtin_amdgcn_udot4(bgr, 0x00264B0Eu, 0u, false);
+        return (int)(((hi << 8) + lo) >> 15);
+    }
+#endif
+};
+
 struct DetBuffers {
     const uint8_t* in;   // [B,H,W,C]
-    uint8_t* gray;       // [B,H,W]
+    uint8_t* gray;       // [B,H,W]; null when the gray image is not to be written (see GraySrc)
+    const uint8_t* graySrc;  // what K6/K7 read gray values from: `gray` (1 byte per pixel) or `in` itself
+    int graySrcC;            // bytes per pixel of graySrc (1 or 3)
     uint8_t* bin;        // [B,H,W] packed scale bits (only when a caller asks for the threshold images), else null
     uint32_t* planes;    // [B,nScales,H,WS] one bit per pixel (bit x&31 of word x>>5), image frame zeroed
     uint64_t* cand;
@@ -170,6 +201,8 @@ struct DetBuffers {
 
 // launchers (each enqueues on `st`, no sync)
 void launch_gray_thresh(const DetCfg& c, const DetBuffers& b, int B, int C, hipStream_t st);
+// true when launch_gray_thresh runs the fused kernel, which can do without writing the gray image
+bool gray_thresh_is_fused(const DetCfg& c);
 void launch_contour_starts(const DetCfg& c, const DetBuffers& b, int B, hipStream_t st);
 void launch_trace(const DetCfg& c, const DetBuffers& b, hipStream_t st);
 void launch_quad_fit(const DetCfg& c, const DetBuffers& b, int B, hipStream_t st);

@@ -56,7 +56,7 @@ __device__ __forceinline__ uint32_t rotate_code(uint32_t code, int n, int r) {
 // side by side; sampling, histogram, votes and dictionary search stay 64 lanes per quad.
 constexpr int kIdBatch = 8;
 
-__global__ __launch_bounds__(64) void k_identify(const uint8_t* __restrict__ gray, QuadRec* __restrict__ quads,
+__global__ __launch_bounds__(64) void k_identify(const uint8_t* __restrict__ gray, int grayC, QuadRec* __restrict__ quads,
                                                  const int* __restrict__ qcount, const uint16_t* __restrict__ dict,
                                                  DetCfg cfg) {
     extern __shared__ __align__(16) uint8_t s_imgs[];  // kIdBatch patches of imgStride bytes (LDS decides the occupancy)
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(64) void k_identify(const uint8_t* __restrict__ gra
     const int nb = cfg.markerSize + 2 * cfg.borderBits;
     const int cell = cfg.cellSize;
     const int S = nb * cell;
-    const uint8_t* __restrict__ img = gray + (size_t)f * H * W;
+    const GraySrc img{gray + (size_t)f * H * W * grayC, grayC, (uint32_t)(H * W - 1)};
     const int imgStride = (S * S + 15) & ~15;
     const int sy0 = lane / S, sx0 = lane - sy0 * S, sqy = 64 / S, sqx = 64 - sqy * S;
 
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(64) void k_identify(const uint8_t* __restrict__ gra
                     int X = (int)rint(fX), Y = (int)rint(fY);
                     X = min(max(X, -32768), 32767);
                     Y = min(max(Y, -32768), 32767);
-                    if (X >= 0 && X < W && Y >= 0 && Y < H) v = img[(size_t)Y * W + X];
+                    if (X >= 0 && X < W && Y >= 0 && Y < H) v = img.at((size_t)Y * W + X);
                 }
                 s_img[p] = (uint8_t)v;
                 atomicAdd(&s_histw[v], 1);
@@ -331,7 +331,7 @@ void launch_identify(const DetCfg& c, const DetBuffers& b, int B, hipStream_t st
     // eight waves per frame, eight quads per wave and round (a frame of the benchmark scene has about 60)
     const int S = (c.markerSize + 2 * c.borderBits) * c.cellSize;
     const size_t lds = (size_t)kIdBatch * ((S * S + 15) & ~15);
-    hipLaunchKernelGGL(k_identify, dim3(8, B), dim3(64), lds, st, b.gray, b.quads, b.qcount, b.dict, c);
+    hipLaunchKernelGGL(k_identify, dim3(8, B), dim3(64), lds, st, b.graySrc, b.graySrcC, b.quads, b.qcount, b.dict, c);
 }
 
 }  // namespace camsync

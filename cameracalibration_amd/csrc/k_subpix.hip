@@ -75,7 +75,7 @@ __device__ __forceinline__ PatchGeom patch_geom(float cx, float cy, int pw, int 
     return g;
 }
 
-// the patch lies inside the image: p = first pixel of patch row i, stride = bytes per image row
+// the patch lies inside the LDS region: p = first pixel of patch row i, stride = bytes per region row
 __device__ __forceinline__ float patch_elem_inside(const uint8_t* __restrict__ p, int stride, const PatchGeom& g, int j) {
     const float t = g.a12 * p[j + 1] + g.a22 * p[j + 1 + stride];
     float prev;
@@ -88,18 +88,29 @@ __device__ __forceinline__ float patch_elem_inside(const uint8_t* __restrict__ p
     return prev + t;
 }
 
-__device__ __forceinline__ float patch_elem(const uint8_t* __restrict__ src, int W, int H, const PatchGeom& g, int i, int j) {
-    if (g.fast) return patch_elem_inside(src + (size_t)(g.ipy + i) * W + g.ipx, W, g, j);
+// any patch, sampled from the image (rare: patches that touch the image border or have left the LDS region)
+__device__ __forceinline__ float patch_elem(const GraySrc& src, int W, int H, const PatchGeom& g, int i, int j) {
+    if (g.fast) {
+        const size_t p = (size_t)(g.ipy + i) * W + g.ipx;
+        const float t = g.a12 * src.at(p + j + 1) + g.a22 * src.at(p + j + 1 + W);
+        float prev;
+        if (j == 0) {
+            prev = (1 - g.a) * (g.b1 * src.at(p) + g.b2 * src.at(p + W));
+        } else {
+            const float tp = g.a12 * src.at(p + j) + g.a22 * src.at(p + j + W);
+            prev = (float)(tp * g.s);
+        }
+        return prev + t;
+    }
     const int y0 = min(max(g.ipy + i, 0), H - 1), y1 = min(max(g.ipy + i + 1, 0), H - 1);
-    const uint8_t* r0 = src + (size_t)y0 * W;
-    const uint8_t* r1 = src + (size_t)y1 * W;
-    if (j < g.rx) return r0[0] * g.b1 + r1[0] * g.b2;
-    if (j >= g.rwid) return r0[W - 1] * g.b1 + r1[W - 1] * g.b2;
+    const size_t r0 = (size_t)y0 * W, r1 = (size_t)y1 * W;
+    if (j < g.rx) return src.at(r0) * g.b1 + src.at(r1) * g.b2;
+    if (j >= g.rwid) return src.at(r0 + W - 1) * g.b1 + src.at(r1 + W - 1) * g.b2;
     const int x0 = g.ipx + j;
-    return r0[x0] * g.a11 + r0[x0 + 1] * g.a12 + r1[x0] * g.a21 + r1[x0 + 1] * g.a22;
+    return src.at(r0 + x0) * g.a11 + src.at(r0 + x0 + 1) * g.a12 + src.at(r1 + x0) * g.a21 + src.at(r1 + x0 + 1) * g.a22;
 }
 
-__global__ __launch_bounds__(64) void k_subpix(const uint8_t* __restrict__ gray, const MarkerRec* __restrict__ markers,
+__global__ __launch_bounds__(64) void k_subpix(const uint8_t* __restrict__ gray, int grayC, const MarkerRec* __restrict__ markers,
                                                unsigned int markerCap, const Counters* __restrict__ ctr,
                                                const float* __restrict__ rawCorners, float* __restrict__ outCorners,
                                                const float* __restrict__ expTab, DetCfg cfg) {
@@ -112,7 +123,7 @@ __global__ __launch_bounds__(64) void k_subpix(const uint8_t* __restrict__ gray,
         const MarkerRec mr = markers[job >> 2];
         const int corner = job & 3;
         const float* mc = rawCorners + ((size_t)mr.frame * kMaxMarkerOut + mr.slot) * 8;
-        const uint8_t* __restrict__ src = gray + (size_t)mr.frame * H * W;
+        const GraySrc src{gray + (size_t)mr.frame * H * W * grayC, grayC, (uint32_t)(H * W - 1)};
         // window from the marker's average module size (unrefined corners)
         float ms = 0.f;
 #pragma unroll
@@ -147,7 +158,7 @@ __global__ __launch_bounds__(64) void k_subpix(const uint8_t* __restrict__ gray,
         if (hasReg) {
             const int qi = 64 / rw, qj = 64 - qi * rw;
             for (int e = lane, i = lane / rw, j = lane - (lane / rw) * rw; e < rw * rh; e += 64) {
-                s_reg[e] = src[(size_t)(ry0 + i) * W + rx0 + j];
+                s_reg[e] = (uint8_t)src.at((size_t)(ry0 + i) * W + rx0 + j);
                 i += qi;
                 j += qj;
                 if (j >= rw) { j -= rw; i++; }
@@ -222,7 +233,7 @@ void launch_subpix(const DetCfg& c, const DetBuffers& b, int B, hipStream_t st) 
     if (!c.subpix) return;
     // one wave per corner (24 per frame in the benchmark scene)
     const unsigned blocks = (unsigned)std::min(std::max(B * 32, 64), 256 * 128);
-    hipLaunchKernelGGL(k_subpix, dim3(blocks), dim3(64), 0, st, b.gray, b.markers, b.markerCap, b.counters,
+    hipLaunchKernelGGL(k_subpix, dim3(blocks), dim3(64), 0, st, b.graySrc, b.graySrcC, b.markers, b.markerCap, b.counters,
                        b.rawCorners, b.outCorners, b.expTab, c);
 }
 

@@ -247,7 +247,7 @@ __global__ __launch_bounds__(TPB) void k_gray_thresh3(const uint8_t* __restrict_
                                                       uint8_t* __restrict__ bin_, uint32_t* __restrict__ planes, int WS, int H, int W, int bandH, int idelta, int nFrames) {
     const int C = MODE == 1 ? 3 : MODE == 2 ? 1 : C_;
     uint8_t* const bin = MODE ? nullptr : bin_;
-    const bool hasGray = MODE ? true : gray != nullptr;
+    const bool hasGray = gray != nullptr;
     constexpr int RMAX = R2;
     constexpr int RING = RMAX + 1;  // rows y-1 .. y-rmax-1; rows y .. y+rmax sit in the register delay line
     static_assert(R0 <= R1 && R1 <= R2 && R2 <= HALO - 1, "radii must be sorted and fit the halo");
@@ -510,8 +510,10 @@ __global__ void k_thresh_generic(const uint8_t* __restrict__ gray, uint8_t* __re
 
 }  // namespace
 
+bool gray_thresh_is_fused(const DetCfg& c) { return c.nScales == 3 && c.radius[0] == 1 && c.radius[1] == 6 && c.radius[2] == 11; }
+
 void launch_gray_thresh(const DetCfg& c, const DetBuffers& b, int B, int C, hipStream_t st) {
-    const bool fast = c.nScales == 3 && c.radius[0] == 1 && c.radius[1] == 6 && c.radius[2] == 11;
+    const bool fast = gray_thresh_is_fused(c);
     if (fast) {
         const int chunks = (c.W + CHUNKW - 1) / CHUNKW;
         // Single-wave workgroups of equal length, 12 resident per CU (registers): the launch runs in rounds, and a last
@@ -535,7 +537,7 @@ void launch_gray_thresh(const DetCfg& c, const DetBuffers& b, int B, int C, hipS
         }
         // 1-D grid, see the kernel: groups of 8 units x strips
         dim3 grid((unsigned)(((long)bands * B + 7) / 8 * 8 * chunks));
-        const bool plain = (c.W % 8) == 0 && !b.bin && b.gray;
+        const bool plain = (c.W % 8) == 0 && !b.bin;
         if (plain && C == 3)
             hipLaunchKernelGGL((k_gray_thresh3<1, 6, 11, 1>), grid, dim3(TPB), 0, st, b.in, C, b.gray, b.bin, b.planes, c.WS, c.H, c.W, bandH, c.idelta, B);
         else if (plain && C == 1)
