@@ -168,6 +168,14 @@ int ensure_staging(camsync_ctx* c) {
     return CAMSYNC_OK;
 }
 
+// The gray image is only written for camsync_gray_threshold and for detector parameters that the fused K1+K2
+// kernel does not cover: allocated on first use (8.5 GB for 4096 1080p frames).
+int ensure_gray(camsync_ctx* c) {
+    if (c->buf.gray) return CAMSYNC_OK;
+    HIPCHK(c, dalloc(&c->buf.gray, (size_t)c->maxB * c->maxH * c->maxW));
+    return CAMSYNC_OK;
+}
+
 int ensure_bin(camsync_ctx* c) {
     if (c->d_bin) return CAMSYNC_OK;
     HIPCHK(c, dalloc(&c->d_bin, (size_t)c->maxB * c->maxH * c->maxW));
@@ -193,10 +201,15 @@ int enqueue_detect(camsync_ctx* c, const uint8_t* d_in, int B, int H, int W, int
     if (cfg.maxPerim > 2 * kCkMax * kCkStride - 4)
         return fail(c, CAMSYNC_E_ARG, "maxMarkerPerimeterRate gives contours of up to %d points, the border follower handles %d",
                     cfg.maxPerim, 2 * kCkMax * kCkStride - 4);
+    const bool fused = gray_thresh_is_fused(cfg);
+    if (!fused) {
+        rcp = ensure_gray(c);
+        if (rcp) return rcp;
+    }
     DetBuffers b = c->buf;
     b.in = d_in;
     b.bin = nullptr;
-    if (gray_thresh_is_fused(cfg)) {  // no gray image: K6 and K7 read the input frame (GraySrc)
+    if (fused) {  // no gray image: K6 and K7 read the input frame (GraySrc)
         b.gray = nullptr;
         b.graySrc = d_in;
         b.graySrcC = C;
@@ -348,8 +361,8 @@ int camsync_create(camsync_ctx** out, int device, int max_h, int max_w, int max_
     HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     const size_t px = (size_t)max_h * max_w, B = (size_t)max_batch;
     DetBuffers& b = c->buf;
-    // the host-input staging buffer and the byte-per-pixel threshold image are allocated on first use
-    HIPCHK(c, dalloc(&b.gray, B * px));
+    // the host-input staging buffer, the gray image and the byte-per-pixel threshold image are allocated on first use
+    b.gray = nullptr;
     b.bin = nullptr;
     c->planeScales = 3;
     HIPCHK(c, dalloc(&b.planes, B * c->planeScales * plane_words(max_h, (max_w + 31) / 32)));
@@ -473,6 +486,8 @@ int camsync_gray_threshold(camsync_ctx* c, const uint8_t* frames, int on_device,
         }
         DetCfg cfg = make_cfg(c, H, W);
         rc = ensure_planes(c, cfg.nScales);
+        if (rc) return rc;
+        rc = ensure_gray(c);
         if (rc) return rc;
         if (bin_out) {
             rc = ensure_bin(c);
