@@ -51,12 +51,13 @@ __device__ __forceinline__ uint32_t luma(uint32_t b, uint32_t g, uint32_t r) {
     return (b * 3735u + g * 19235u + r * 9798u + 16384u) >> 15;
 }
 
-// luma of the pixel whose B,G,R are bytes 0,1,2 of p: the weights split as w = 256 wh + wl
-// (3735 = 14*256+151, 19235 = 75*256+35, 9798 = 38*256+70), each half a byte dot product.
-__device__ __forceinline__ uint32_t luma_dot(uint32_t p) {
-    const uint32_t lo = __builtin_amdgcn_udot4(p, 0x00462397u, 16384u, false);
-    const uint32_t hi = __builtin_amdgcn_udot4(p, 0x00264B0Eu, 0u, false);
-    return ((hi << 8) + lo) >> 15;
+// luma of the pixel whose B,G,R are bytes 0,1,2 of p, left in byte 2 of the result.  The weights are doubled, so
+// that the rounding shift is 16 bits and the gray value a whole byte that a byte permute can pick up:
+// (2 (3735 B + 19235 G + 9798 R) + 2^15) >> 16; they split as 2 w = 256 wh + wl (7470 = 29*256+46,
+// 38470 = 150*256+70, 19596 = 76*256+140), each half a byte dot product, the second one on top of the first.
+__device__ __forceinline__ uint32_t luma_dot_b2(uint32_t p) {
+    const uint32_t hi = __builtin_amdgcn_udot4(p, 0x004C961Du, 0u, false);
+    return __builtin_amdgcn_udot4(p, 0x008C462Eu, (hi << 8) + 32768u, false);
 }
 
 // The 24 (C == 3) or 8 (C == 1) input bytes of columns xbase..xbase+7 of one row, as loaded; converting them
@@ -85,16 +86,17 @@ __device__ __forceinline__ uint2 gray_of(const RawRow& q, int C, int W, int xbas
         const uint2 a = q.a, b = q.b, c = q.c;
         uint32_t g[8];
         // pixel i starts at byte 3 i of the 24 bytes a.x a.y b.x b.y c.x c.y
-        g[0] = luma_dot(a.x);
-        g[1] = luma_dot(__builtin_amdgcn_alignbyte(a.y, a.x, 3));
-        g[2] = luma_dot(__builtin_amdgcn_alignbyte(b.x, a.y, 2));
-        g[3] = luma_dot(__builtin_amdgcn_alignbyte(b.y, b.x, 1));
-        g[4] = luma_dot(b.y);
-        g[5] = luma_dot(__builtin_amdgcn_alignbyte(c.x, b.y, 3));
-        g[6] = luma_dot(__builtin_amdgcn_alignbyte(c.y, c.x, 2));
-        g[7] = luma_dot(c.y >> 8);
-        r.x = g[0] | (g[1] << 8) | (g[2] << 16) | (g[3] << 24);
-        r.y = g[4] | (g[5] << 8) | (g[6] << 16) | (g[7] << 24);
+        g[0] = luma_dot_b2(a.x);
+        g[1] = luma_dot_b2(__builtin_amdgcn_alignbyte(a.y, a.x, 3));
+        g[2] = luma_dot_b2(__builtin_amdgcn_alignbyte(b.x, a.y, 2));
+        g[3] = luma_dot_b2(__builtin_amdgcn_alignbyte(b.y, b.x, 1));
+        g[4] = luma_dot_b2(b.y);
+        g[5] = luma_dot_b2(__builtin_amdgcn_alignbyte(c.x, b.y, 3));
+        g[6] = luma_dot_b2(__builtin_amdgcn_alignbyte(c.y, c.x, 2));
+        g[7] = luma_dot_b2(c.y >> 8);
+        // byte 2 of four results -> one word
+        r.x = __builtin_amdgcn_perm(g[1], g[0], 0x0C0C0602u) | __builtin_amdgcn_perm(g[3], g[2], 0x06020C0Cu);
+        r.y = __builtin_amdgcn_perm(g[5], g[4], 0x0C0C0602u) | __builtin_amdgcn_perm(g[7], g[6], 0x06020C0Cu);
     } else {
         r = q.a;
     }
