@@ -280,7 +280,8 @@ __global__ __launch_bounds__(TPB) void k_gray_thresh3(const uint8_t* __restrict_
     const bool aligned = MODE ? true : (W % 8) == 0;
     const size_t frameOff = (size_t)f * H * W;
     const bool inOut = (tid >= HALO / PX) && (tid < TPB - HALO / PX) && xbase < W;  // produces output
-    const bool fullOut = inOut && (xbase + 7 < W) && aligned;
+    // (MODE 1 / 2: the width is a multiple of 8, so a group that starts inside the image lies inside it: no per-byte path)
+    const bool fullOut = MODE ? inOut : inOut && (xbase + 7 < W) && aligned;
     constexpr int K0 = (2 * R0 + 1) * (2 * R0 + 1), K1 = (2 * R1 + 1) * (2 * R1 + 1), K2 = (2 * R2 + 1) * (2 * R2 + 1);
     const int c0 = ((2 * idelta - 1) * K0 + 1) >> 1, c1 = ((2 * idelta - 1) * K1 + 1) >> 1, c2 = ((2 * idelta - 1) * K2 + 1) >> 1;
 
@@ -396,7 +397,7 @@ __global__ __launch_bounds__(TPB) void k_gray_thresh3(const uint8_t* __restrict_
             // one byte per scale, bit i = pixel xbase+i
             const uint32_t pm0 = thresh_bits(s0, cv, K0), pm1 = thresh_bits(s1, cv, K1), pm2 = thresh_bits(s2, cv, K2);
             const size_t off = frameOff + (size_t)y * W + xbase;
-            if (fullOut) {
+            if (MODE != 0 || fullOut) {
                 if (bin) {
                     uint32_t ob[8];
 #pragma unroll
