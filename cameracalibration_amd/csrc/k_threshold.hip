@@ -80,6 +80,32 @@ __device__ __forceinline__ RawRow issue_row(const uint8_t* __restrict__ in, int 
     return r;
 }
 
+// issue_row for 3 channels with the lane's byte offset in the row (3 x its clamped first column) worked out once:
+// the row is the same for every lane, so the loads take a scalar base and that 32-bit lane offset, and the
+// 64-bit address arithmetic per lane and row (a dozen vector instructions in a kernel bound by them) goes away.
+// Written so that the compiler keeps that form: the base goes through an empty asm as a pointer to global memory
+// (else it re-associates base + offset and hoists the lane part as a 64-bit lane address), and so does the lane
+// offset (widened to 64 bits outside the row loop it no longer looks like a 32-bit offset).
+__device__ __forceinline__ RawRow issue_row3(const uint8_t* __restrict__ in, size_t rowOff, uint32_t laneByte) {
+    using GBytes = const __attribute__((address_space(1))) uint8_t*;
+    using GWords = const __attribute__((address_space(1))) uint64_t*;
+    const uint64_t rowByte = rowOff * 3;
+    // (the builtin returns int: without the casts the low half would be sign-extended over the high one)
+    const uint32_t rowLo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)rowByte);
+    const uint32_t rowHi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(rowByte >> 32));
+    GBytes base = (GBytes)in + (((uint64_t)rowHi << 32) | (uint64_t)rowLo);
+    asm("" : "+s"(base));
+    uint32_t o = laneByte;
+    asm volatile("" : "+v"(o));
+    GWords p = (GWords)(base + o);
+    const uint64_t pa = p[0], pb = p[1], pc = p[2];
+    RawRow r;
+    r.a = make_uint2((uint32_t)pa, (uint32_t)(pa >> 32));
+    r.b = make_uint2((uint32_t)pb, (uint32_t)(pb >> 32));
+    r.c = make_uint2((uint32_t)pc, (uint32_t)(pc >> 32));
+    return r;
+}
+
 __device__ __forceinline__ uint2 gray_of(const RawRow& q, int C, int W, int xbase) {
     uint2 r;
     if (C == 3) {
@@ -282,6 +308,9 @@ __global__ __launch_bounds__(TPB) void k_gray_thresh3(const uint8_t* __restrict_
     const bool inOut = (tid >= HALO / PX) && (tid < TPB - HALO / PX) && xbase < W;  // produces output
     // (MODE 1 / 2: the width is a multiple of 8, so a group that starts inside the image lies inside it: no per-byte path)
     const bool fullOut = MODE ? inOut : inOut && (xbase + 7 < W) && aligned;
+    // MODE 1: byte offset of the lane's (clamped) group in a row, see issue_row3
+    const uint32_t laneByte = (uint32_t)(min(max(xbase, 0), W - 8) * 3);
+    auto issue = [&](size_t rowOff) { return MODE == 1 ? issue_row3(in, rowOff, laneByte) : issue_row(in, C, W, rowOff, aligned ? xbase : 0); };
     constexpr int K0 = (2 * R0 + 1) * (2 * R0 + 1), K1 = (2 * R1 + 1) * (2 * R1 + 1), K2 = (2 * R2 + 1) * (2 * R2 + 1);
     const int c0 = ((2 * idelta - 1) * K0 + 1) >> 1, c1 = ((2 * idelta - 1) * K1 + 1) >> 1, c2 = ((2 * idelta - 1) * K2 + 1) >> 1;
 
@@ -352,12 +381,12 @@ __global__ __launch_bounds__(TPB) void k_gray_thresh3(const uint8_t* __restrict_
     for (int k = RMAX; k < RMAX + UNR; k++) A[k] = make_uint2(0, 0);
     RawRow pend[UNR];
 #pragma unroll
-    for (int k = 0; k < UNR; k++) pend[k] = issue_row(in, C, W, rowOffOf(y0 + RMAX + k), aligned ? xbase : 0);
+    for (int k = 0; k < UNR; k++) pend[k] = issue(rowOffOf(y0 + RMAX + k));
     // one row; j = its place in the group (a compile-time constant, so that A and pend are registers)
     auto do_row = [&](const int y, auto jc) {
         constexpr int j = decltype(jc)::value;
         A[RMAX + j] = aligned ? gray_of(pend[j], C, W, xbase) : load_gray8(in, C, W, rowOffOf(y + RMAX), xbase, false);
-        pend[j] = issue_row(in, C, W, rowOffOf(y + RMAX + UNR), aligned ? xbase : 0);
+        pend[j] = issue(rowOffOf(y + RMAX + UNR));
 
         uint32_t a[4], b[4];
         // every window takes in the row r_k below the centre (registers) and drops the row r_k + 1 above it (ring)
