@@ -40,6 +40,10 @@ def main():
     from tests import _data
 
     out = {}
+    # the mirror prints what the reference prints ("Found calibration file ..."): keep stdout for the JSON line
+    import contextlib
+    _quiet = contextlib.redirect_stdout(sys.stderr)
+    _quiet.__enter__()
 
     if args.frames4k > 0:
         # ---- configs[2], one GPU: 4K, 40 markers per frame ----
@@ -135,6 +139,7 @@ def main():
     except Exception as e:
         out["batch8_1920x1080_processArucoBatch"] = {"error": "%s: %s" % (type(e).__name__, e)}
 
+    _quiet.__exit__(None, None, None)
     print(json.dumps(out))
 
 
