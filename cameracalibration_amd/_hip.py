@@ -87,6 +87,7 @@ def load_library() -> C.CDLL:
         lib.camsync_gray_threshold.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp]
         lib.camsync_detect_batch.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, i32, vp, vp]
         lib.camsync_debug_counts.argtypes = [vp, i32, vp]
+        lib.camsync_debug_lists.argtypes = [vp, vp, vp]
         lib.camsync_debug_quads.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp]
         lib.camsync_debug_contours.argtypes = [vp, i32, i32, vp, vp, vp, vp]
         lib.camsync_debug_points.argtypes = [vp, i32, i32, vp]
@@ -226,6 +227,14 @@ class Context:
         self._check(self._lib.camsync_debug_counts(self._h, frame, _ptr(out)))
         return dict(candidates=int(out[0]), contours=int(out[1]), points=int(out[2]), markers=int(out[3]),
                     overflow=int(out[4]), quads=int(out[5]), long_candidates=int(out[6]), queue_head=int(out[7]))
+
+    LIST_NAMES = ("starts", "long_starts", "contours", "points", "store_tasks", "chain_chunks", "copy_tasks", "tail")
+
+    def debug_lists(self):
+        """{list: (entries used by the last chunk, capacity)} of the chunk-wide scratch lists."""
+        used = np.zeros(8, np.uint32); cap = np.zeros(8, np.uint32)
+        self._check(self._lib.camsync_debug_lists(self._h, _ptr(used), _ptr(cap)))
+        return {n: (int(u), int(k)) for n, u, k in zip(self.LIST_NAMES, used, cap)}
 
     def debug_quads(self, frame=0, cap=1024):
         c = np.zeros((cap, 4, 2), np.float32)

@@ -271,9 +271,9 @@ int check_overflow(camsync_ctx* c) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (h.overflow)
         return fail(c, CAMSYNC_E_CAPACITY,
-                    "detection scratch overflow (mask 0x%x: 1 starts, 2 contours, 4 points, 8 quads, 32 markers, 64 store tasks); "
-                    "candidates %u contours %u points %u",
-                    h.overflow, h.nCand, h.nContours, h.nPool);
+                    "detection scratch overflow (mask 0x%x: 1 starts, 2 contours, 4 points, 8 quads, 32 markers, 64 store/copy tasks, "
+                    "128 bad contour record, 256 chain chunks); candidates %u contours %u points %u chain %u copies %u",
+                    h.overflow, h.nCand, h.nContours, h.nPool, h.nChain, h.nCopy);
     return CAMSYNC_OK;
 }
 
@@ -382,7 +382,8 @@ int camsync_create(camsync_ctx** out, int device, int max_h, int max_w, int max_
     HIPCHK(c, dalloc(&b.ckpt, (size_t)kTraceWaves * 32 * 2 * kCkMax));
     // step directions of the borders the decide passes follow (kept or not): one 128-byte chunk per 256 steps and at
     // least one per border and direction; copy tasks: one per piece of a kept border
-    b.chainCap = (unsigned)std::min<size_t>(B * 2048 + kLongWaves * 256, 0x03FFFFFFu);
+    // (measured on the 4K scene of BASELINE configs[2]: 2500 chunks per frame; budget px / 2048 = 4050)
+    b.chainCap = (unsigned)std::min<size_t>(B * std::max<size_t>(2048, px / 2048) + kLongWaves * 256, 0x03FFFFFFu);
     HIPCHK(c, dalloc(&b.chain, (size_t)b.chainCap * 32));
     b.copyCap = b.taskCap;
     HIPCHK(c, dalloc(&b.copies, b.copyCap));
@@ -635,7 +636,6 @@ int camsync_detect_pnp_resident(camsync_ctx* c, const uint8_t* d_frames, int B, 
     HIPCHK(c, hipMemcpyAsync(c->d_K, K, sizeof(double) * 9, hipMemcpyHostToDevice, c->stream));
     if (ndist) HIPCHK(c, hipMemcpyAsync(c->d_dist, dist, sizeof(double) * ndist, hipMemcpyHostToDevice, c->stream));
     const size_t px = (size_t)H * W;
-    const int mm = std::min(max_markers, kMaxMarkerOut);
     unsigned int overflowSeen = 0;
     for (int b0 = 0; b0 < B; b0 += c->maxB) {
         const int nb = std::min(c->maxB, B - b0);
@@ -651,11 +651,9 @@ int camsync_detect_pnp_resident(camsync_ctx* c, const uint8_t* d_frames, int B, 
         launch_pnp(a, c->stream);
         debug_stage(c->stream, "pnp");
         if (c->timing) (void)hipEventRecord(c->ev[8], c->stream);
-        HIPCHK(c, hipMemcpy2DAsync(d_ids + (size_t)b0 * max_markers, sizeof(int32_t) * max_markers, c->buf.outIds,
-                                   sizeof(int32_t) * kMaxMarkerOut, sizeof(int32_t) * mm, nb, hipMemcpyDeviceToDevice, c->stream));
-        HIPCHK(c, hipMemcpy2DAsync(d_corners + (size_t)b0 * max_markers * 8, sizeof(float) * 8 * max_markers, c->buf.outCorners,
-                                   sizeof(float) * 8 * kMaxMarkerOut, sizeof(float) * 8 * mm, nb, hipMemcpyDeviceToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(d_counts + b0, c->buf.outCounts, sizeof(int32_t) * nb, hipMemcpyDeviceToDevice, c->stream));
+        // ids, corners and counts (clamped to max_markers) in the caller's layout
+        launch_export_markers(c->buf, nb, max_markers, d_ids + (size_t)b0 * max_markers, d_corners + (size_t)b0 * max_markers * 8,
+                              d_counts + b0, c->stream);
         // the scratch lists are reused by the next chunk: the stream orders that; overflow is checked per chunk
         Counters h;
         HIPCHK(c, hipMemcpyAsync(&h, c->buf.counters, sizeof h, hipMemcpyDeviceToHost, c->stream));
@@ -664,7 +662,10 @@ int camsync_detect_pnp_resident(camsync_ctx* c, const uint8_t* d_frames, int B, 
         rc = collect_timers(c, 7);
         if (rc) return rc;
     }
-    if (overflowSeen) return fail(c, CAMSYNC_E_CAPACITY, "detection scratch overflow (mask 0x%x)", overflowSeen);
+    if (overflowSeen)
+        return fail(c, CAMSYNC_E_CAPACITY,
+                    "detection scratch overflow (mask 0x%x: 1 starts, 2 contours, 4 points, 8 quads, 32 markers, 64 store/copy tasks, "
+                    "128 bad contour record, 256 chain chunks)", overflowSeen);
     return CAMSYNC_OK;
 }
 
@@ -705,6 +706,19 @@ int camsync_debug_counts(camsync_ctx* c, int frame, int32_t out[8]) {
     if (frame >= 0 && frame < c->lastB) HIPCHK(c, hipMemcpy(&q, c->buf.qcount + frame, sizeof q, hipMemcpyDeviceToHost));
     out[0] = (int32_t)h.nCand; out[1] = (int32_t)h.nContours; out[2] = (int32_t)h.nPool; out[3] = (int32_t)h.nMarkers;
     out[4] = (int32_t)h.overflow; out[5] = q; out[6] = (int32_t)h.nLong; out[7] = (int32_t)h.qDecide;
+    return CAMSYNC_OK;
+}
+
+int camsync_debug_lists(camsync_ctx* c, uint32_t used[8], uint32_t cap[8]) {
+    if (!c || !used || !cap) return CAMSYNC_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    Counters h;
+    HIPCHK(c, hipMemcpy(&h, c->buf.counters, sizeof h, hipMemcpyDeviceToHost));
+    const DetBuffers& b = c->buf;
+    const uint32_t u[8] = {h.nCand, h.nLong, h.nContours, h.nPool, h.nTasks, h.nChain, h.nCopy, h.nTail};
+    const uint32_t k[8] = {b.candCap, b.candCap, b.contourCap, b.poolCap, b.taskCap, b.chainCap, b.copyCap,
+                           (uint32_t)(kTraceWaves * kTailPairs)};
+    for (int i = 0; i < 8; i++) { used[i] = u[i]; cap[i] = k[i]; }
     return CAMSYNC_OK;
 }
 
@@ -763,6 +777,8 @@ int camsync_debug_points(camsync_ctx* c, int frame, int max_points, int32_t* xy)
     std::vector<uint32_t> pts;
     for (unsigned i = 0; i < n; i++) {
         if ((int)h[i].frame != frame) continue;
+        if (h[i].off >= c->buf.poolCap || h[i].len > c->buf.poolCap - h[i].off)
+            return fail(c, CAMSYNC_E_CAPACITY, "contour record %u points outside the pool (off %u len %u)", i, h[i].off, h[i].len);
         pts.resize(h[i].len);
         if (h[i].len) HIPCHK(c, hipMemcpy(pts.data(), c->buf.pool + h[i].off, sizeof(uint32_t) * h[i].len, hipMemcpyDeviceToHost));
         for (uint32_t j = 0; j < h[i].len; j++, k++)

@@ -120,7 +120,7 @@ struct Counters {
     unsigned int nContours;
     unsigned int nPool;
     unsigned int nMarkers;
-    unsigned int overflow;  // bit0 cand, bit1 contours, bit2 pool, bit3 quads, bit4 sel, bit5 markers
+    unsigned int overflow;  // 1 starts, 2 contours, 4 points, 8 quads, 32 markers, 64 store/copy tasks, 128 bad contour record, 256 chain chunks
     unsigned int nLong;     // candidates handed from the short-trace pass to the long-trace pass
     unsigned int qDecide;   // work-queue heads of the long-border kernels (lanes fetch their next border here)
     unsigned int qStore;
@@ -209,6 +209,8 @@ void launch_quad_fit(const DetCfg& c, const DetBuffers& b, int B, hipStream_t st
 void launch_identify(const DetCfg& c, const DetBuffers& b, int B, hipStream_t st);
 void launch_select(const DetCfg& c, const DetBuffers& b, int B, hipStream_t st);
 void launch_subpix(const DetCfg& c, const DetBuffers& b, int B, hipStream_t st);
+void launch_export_markers(const DetBuffers& b, int B, int maxMarkers, int32_t* dIds, float* dCorners, int32_t* dCounts,
+                           hipStream_t st);
 
 // pose
 struct PnpArgs {

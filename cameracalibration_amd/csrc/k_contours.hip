@@ -890,7 +890,7 @@ __global__ __launch_bounds__(64) void k_trace_decide(const uint32_t* __restrict_
             const unsigned long long bal = __ballot(newPiece);
             if (bal) {
                 uint2 unused;
-                const unsigned int base = chainA.take((unsigned int)__popcll(bal), kChainBlock, &ctr->nChain, chainCap, 4u, ctr, lane, unused);
+                const unsigned int base = chainA.take((unsigned int)__popcll(bal), kChainBlock, &ctr->nChain, chainCap, 256u, ctr, lane, unused);
                 if (newPiece) {
                     chChunk = base == ~0u ? ~0u : base + (unsigned int)__popcll(bal & ((1ull << lane) - 1ull));
                     chFail = chFail || base == ~0u;

@@ -26,8 +26,9 @@ struct IPt { int x, y; };
 __device__ __forceinline__ IPt unpack_pt(uint32_t p) { return IPt{(int)(p & 0xFFFFu), (int)(p >> 16)}; }
 
 __global__ __launch_bounds__(64) void k_quad_fit(const ContourRec* __restrict__ contours, unsigned int contourCap,
-                                                 const uint32_t* __restrict__ pool, QuadRec* __restrict__ quads,
-                                                 int* __restrict__ qcount, Counters* __restrict__ ctr, DetCfg cfg) {
+                                                 const uint32_t* __restrict__ pool, unsigned int poolCap, int B,
+                                                 QuadRec* __restrict__ quads, int* __restrict__ qcount,
+                                                 Counters* __restrict__ ctr, DetCfg cfg) {
     __shared__ int s_stack[32][2];
     __shared__ IPt s_dst[16];
     // the points of the contour, when they fit: every Douglas-Peucker pass depends on the result of the one
@@ -41,6 +42,12 @@ __global__ __launch_bounds__(64) void k_quad_fit(const ContourRec* __restrict__ 
         const ContourRec rec = contours[ci];
         const int n = (int)rec.len;
         if (n <= 0 || n > cfg.maxPerim) continue;  // a slot a border-follower wave reserved and did not use (kept contours never exceed maxPerim)
+        // a record is only trusted as far as it can be checked: its frame indexes qcount/quads, its points must lie
+        // inside the pool (a record that fails this is a bug upstream; the call then fails with CAMSYNC_E_CAPACITY)
+        if (rec.frame >= (unsigned int)B || rec.off >= poolCap || rec.len > poolCap - rec.off) {
+            if (lane == 0) atomicOr(&ctr->overflow, 128u);
+            continue;
+        }
         const uint32_t* __restrict__ G = pool + rec.off;
         const bool cached = n <= kCacheN;
         if (cached)
@@ -232,8 +239,8 @@ void launch_quad_fit(const DetCfg& c, const DetBuffers& b, int B, hipStream_t st
     // one wave per contour, a few hundred contours per frame; far more blocks than fit at once keeps the CUs
     // evenly loaded (contours differ a lot in length)
     const unsigned blocks = (unsigned)std::min(std::max(B * 128, 256), 256 * 128);
-    hipLaunchKernelGGL(k_quad_fit, dim3(blocks), dim3(64), 0, st, b.contours, b.contourCap, b.pool, b.quads, b.qcount,
-                       b.counters, c);
+    hipLaunchKernelGGL(k_quad_fit, dim3(blocks), dim3(64), 0, st, b.contours, b.contourCap, b.pool, b.poolCap, B, b.quads,
+                       b.qcount, b.counters, c);
 }
 
 }  // namespace camsync

@@ -12,6 +12,8 @@
 // dependent bookkeeping runs on lane 0.
 #include "internal.h"
 
+#include <algorithm>
+
 namespace camsync {
 
 namespace {
@@ -306,7 +308,36 @@ __global__ __launch_bounds__(64) void k_select(const QuadRec* __restrict__ quads
     }
 }
 
+// Results of a chunk in the caller's layout (camsync_detect_pnp_resident): ids [B,maxMarkers], corners
+// [B,maxMarkers,8], counts [B] clamped to the columns the caller gave.  Lane = one marker slot.
+__global__ __launch_bounds__(256) void k_export_markers(const int32_t* __restrict__ outIds, const float* __restrict__ outCorners,
+                                                        const int32_t* __restrict__ outCounts, int B, int maxMarkers,
+                                                        int32_t* __restrict__ dIds, float* __restrict__ dCorners,
+                                                        int32_t* __restrict__ dCounts) {
+    const int mm = min(maxMarkers, kMaxMarkerOut);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * mm) return;
+    const int f = i / mm, m = i - f * mm;
+    const int n = min(max(outCounts[f], 0), mm);
+    if (m == 0) dCounts[f] = n;
+    if (m >= n) return;
+    dIds[(size_t)f * maxMarkers + m] = outIds[(size_t)f * kMaxMarkerOut + m];
+    const float4* src = reinterpret_cast<const float4*>(outCorners + ((size_t)f * kMaxMarkerOut + m) * 8);
+    float* dst = dCorners + ((size_t)f * maxMarkers + m) * 8;  // the caller's buffer need not be 16-byte aligned
+    const float4 a = src[0], b = src[1];
+    dst[0] = a.x; dst[1] = a.y; dst[2] = a.z; dst[3] = a.w;
+    dst[4] = b.x; dst[5] = b.y; dst[6] = b.z; dst[7] = b.w;
+}
+
 }  // namespace
+
+void launch_export_markers(const DetBuffers& b, int B, int maxMarkers, int32_t* dIds, float* dCorners, int32_t* dCounts,
+                           hipStream_t st) {
+    const int mm = std::min(maxMarkers, kMaxMarkerOut);
+    const unsigned blocks = (unsigned)(((size_t)B * mm + 255) / 256);
+    hipLaunchKernelGGL(k_export_markers, dim3(blocks), dim3(256), 0, st, b.outIds, b.outCorners, b.outCounts, B, maxMarkers,
+                       dIds, dCorners, dCounts);
+}
 
 void launch_select(const DetCfg& c, const DetBuffers& b, int B, hipStream_t st) {
     hipLaunchKernelGGL(k_select<256>, dim3(B), dim3(64), 0, st, b.quads, b.qcount, c, b.outIds, b.outCorners, b.rawCorners, b.outCounts,

@@ -53,12 +53,13 @@ def sheet_bounds(sheet, margin):
     return xs0, xs1, ys0, ys1
 
 
-def look_at_pose(rng: np.random.Generator, center, dist_range=(400.0, 900.0), tilt_range=(0.0, 50.0)):
+def look_at_pose(rng: np.random.Generator, center, dist_range=(400.0, 900.0), tilt_range=(0.0, 50.0),
+                 roll_range=(0.0, 2 * math.pi)):
     """Random camera pose looking at `center` (sheet coordinates, z = 0)."""
     d = rng.uniform(*dist_range)
     tilt = math.radians(rng.uniform(*tilt_range))
     az = rng.uniform(0, 2 * math.pi)
-    roll = rng.uniform(0, 2 * math.pi)
+    roll = rng.uniform(*roll_range)
     # camera position in world
     c = np.array([center[0] + d * math.sin(tilt) * math.cos(az), center[1] + d * math.sin(tilt) * math.sin(az),
                   d * math.cos(tilt)])
@@ -121,20 +122,23 @@ def render_sheet(sheet, K, R, t, H, W, seed=0, ss=3, noise_sigma=4.0, device="cp
     return out.round().clamp(0, 255).to(torch.uint8)
 
 
-def v1_frame(idx, K, H=1080, W=1920, base_seed=1234, device="cpu", ss=3):
+def v1_frame(idx, K, H=1080, W=1920, base_seed=1234, device="cpu", ss=3, noise_sigma=4.0):
     """Config-2 style frame: the v1 sheet (ids 10..15) from a random pose.
     Returns (bgr uint8 tensor [H,W,3], R, t)."""
     rng = np.random.default_rng(base_seed + idx)
     R, t = look_at_pose(rng, (95.0, -135.0))
-    return render_sheet(SHEET_V1, K, R, t, H, W, seed=base_seed + idx, device=device, ss=ss), R, t
+    return render_sheet(SHEET_V1, K, R, t, H, W, seed=base_seed + idx, device=device, ss=ss, noise_sigma=noise_sigma), R, t
 
 
-def grid_frame(idx, K, H=2160, W=3840, base_seed=4321, device="cpu", ss=2):
-    """Config-3 style frame: 40 markers on a jittered 8x5 grid, mild perspective."""
+def grid_frame(idx, K, H=2160, W=3840, base_seed=4321, device="cpu", ss=2, noise_sigma=4.0):
+    """Config-3 style frame: 40 markers on a jittered 8x5 grid (the 34 sheet-verified ids, six of them twice), mild
+    perspective.  The roll keeps the sheet's long side along the image's (a free roll puts a third of the markers
+    outside a 16:9 frame), and the distance keeps the whole sheet inside it: all 40 markers are visible."""
     rng = np.random.default_rng(base_seed + idx)
     sheet = sheet_grid(rng)
-    R, t = look_at_pose(rng, (400.0, -250.0), dist_range=(700.0, 800.0), tilt_range=(0.0, 20.0))
-    return render_sheet(sheet, K, R, t, H, W, seed=base_seed + idx, device=device, ss=ss), sheet, R, t
+    R, t = look_at_pose(rng, (400.0, -250.0), dist_range=(800.0, 900.0), tilt_range=(0.0, 15.0),
+                        roll_range=(math.pi / 2 - 0.15, math.pi / 2 + 0.15))
+    return render_sheet(sheet, K, R, t, H, W, seed=base_seed + idx, device=device, ss=ss, noise_sigma=noise_sigma), sheet, R, t
 
 
 def calib_views(V=2000, seed=42, rational=True, noise=0.3, grid=(7, 7)):

@@ -118,6 +118,12 @@ int camsync_detect_batch(camsync_ctx* ctx, const uint8_t* frames, int on_device,
  *   camsync_debug_points   the points of those contours, concatenated in the same order: xy i32 [n,2]
  * The quad/contour/point calls return the number of elements available (may exceed the capacity passed), or <0. */
 int camsync_debug_counts(camsync_ctx* ctx, int frame, int32_t out[8]);
+/* Fill level and capacity of the chunk-wide scratch lists after the last chunk (capacity planning; a list that is
+ * fuller than its capacity made the call fail with CAMSYNC_E_CAPACITY): [0] contour-start candidates, [1] candidates
+ * of the long-border pass, [2] contour records, [3] contour points, [4] store tasks (short borders), [5] chain
+ * chunks (128 bytes per 256 steps of a long border), [6] copy tasks, [7] borders handed to the tail pass.  The
+ * counters include the blocks the border-follower waves reserve and leave partly unused. */
+int camsync_debug_lists(camsync_ctx* ctx, uint32_t used[8], uint32_t cap[8]);
 int camsync_debug_quads(camsync_ctx* ctx, int frame, int max_quads, float* corners,
                         int32_t* scale, int32_t* scan_key, int32_t* contour_len,
                         int32_t* id, int32_t* rot);
