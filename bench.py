@@ -79,6 +79,63 @@ def cpu_baseline(sample_frames, anchors_ids, anchor_obj, K, dist, threads):
     return len(sample_frames) / dt, n
 
 
+def launch_ranks(n, argv):
+    """Start n ranks of this script (one process per GPU) and wait for them.  The parent never touches a GPU: the
+    children are started before any torch / HIP call, with RANK, LOCAL_RANK, WORLD_SIZE and the rendezvous address in
+    their environment (what `python -m torch.distributed.run --nproc-per-node n` would set).  Rank 0 inherits stdout
+    (the JSON line).  Returns the worst exit code."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0:
+                    rc = rc or code
+                    for q in pending:  # a rank died: the others would wait in a collective for ever
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+def selftest_rank(args, world, rank):
+    """CAMSYNC_BENCH_SELFTEST=1: the rank plumbing of this script without a GPU (tests/test_bench_launch.py):
+    rendezvous over gloo, barrier, max-over-ranks of a per-rank time, one JSON line from rank 0."""
+    import torch
+    import torch.distributed as dist_mod
+    dist_mod.init_process_group("gloo", rank=rank, world_size=world)
+    dist_mod.barrier()
+    tt = torch.tensor([1.0 + rank], dtype=torch.float64)
+    dist_mod.all_reduce(tt, op=dist_mod.ReduceOp.MAX)
+    seen = torch.zeros(world, dtype=torch.int64)
+    seen[rank] = int(os.environ["LOCAL_RANK"]) + 1
+    dist_mod.all_reduce(seen)
+    if rank == 0:
+        print(json.dumps({"selftest": True, "n_gpus": world, "max_dt": float(tt.item()), "local_ranks": (seen - 1).tolist(),
+                          "steps": args.steps, "warmup": args.warmup}))
+    dist_mod.barrier()
+    dist_mod.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -94,14 +151,26 @@ def main():
     ap.add_argument("--calib-views", type=int, default=2000)
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist_mod
-
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: this process becomes the launcher (no torch, no HIP here)
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if os.environ.get("CAMSYNC_BENCH_SELFTEST"):
+        return selftest_rank(args, world, rank)
+
+    import torch
+    import torch.distributed as dist_mod
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (libcamsync_hip has no CPU fallback)")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} wants GPU {local_rank}, the node has {torch.cuda.device_count()}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
