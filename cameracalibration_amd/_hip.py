@@ -27,6 +27,12 @@ class CamsyncError(RuntimeError):
         self.code = code
 
 
+# camsync_allreduce_fn: int (*)(void* user, double* d_buf, int n, void* hip_stream)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p)
+CALIB_WORK_DOUBLES = 192
+E_COMM = -6
+
+
 class Params(C.Structure):
     """camsync_params — cv.aruco.DetectorParameters as aruco.py:249-254 sets it."""
 
@@ -100,6 +106,8 @@ def load_library() -> C.CDLL:
         lib.camsync_detect_pnp_resident.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, i32, vp, vp, i32,
                                                     i32, vp, vp, vp, vp, vp, vp]
         lib.camsync_calibrate.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp]
+        lib.camsync_calibrate_dist.argtypes = [vp, vp, vp, i32, i32, C.c_int64, i32, i32, i32, i32, ALLREDUCE_FN, vp, vp,
+                                               vp, vp, vp, vp, vp, vp]
         lib.camsync_calib_begin.argtypes = [vp, vp, vp, i32, i32, i32]
         lib.camsync_calib_focal_acc.argtypes = [vp, i32, i32, vp]
         lib.camsync_calib_set_intrinsics.argtypes = [vp, vp, i32]
@@ -330,6 +338,38 @@ class Context:
         self._check(self._lib.camsync_calibrate(self._h, _ptr(obj), _ptr(img), V, P, W, H, 1 if rational else 0, max_iter,
                                                 _ptr(K), _ptr(dist), _ptr(rvecs), _ptr(tvecs), C.byref(rms), C.byref(iters)))
         return rms.value, K, dist, rvecs, tvecs, iters.value
+
+    def calibrate_dist(self, obj, img, n_views_total, image_size, rational=False, max_iter=30, allreduce=None, d_work=None):
+        """camsync_calibrate_dist: this rank's views (possibly none) of a calibration over `n_views_total` views.
+        `allreduce(d_buf_ptr, n, hip_stream)` must sum n device doubles at d_buf_ptr over the ranks in place (see
+        include/camsync.h); None = single rank.  d_work: device pointer of CALIB_WORK_DOUBLES doubles, or None."""
+        obj = np.ascontiguousarray(obj, dtype=np.float32)
+        V = obj.shape[0]
+        P = obj.shape[1]
+        img = np.ascontiguousarray(img, dtype=np.float32).reshape(V, P, 2)
+        W, H = image_size
+        K = np.zeros((3, 3)); dist = np.zeros(8 if rational else 5)
+        rvecs = np.zeros((max(V, 1), 3)); tvecs = np.zeros((max(V, 1), 3))
+        rms = C.c_double(0); iters = C.c_int32(0)
+        failure = []
+
+        def _cb(user, d_buf, n, stream):
+            try:
+                allreduce(int(d_buf), int(n), int(stream or 0))
+                return 0
+            except BaseException as e:  # an exception must not unwind through the C frames
+                failure.append(e)
+                return 1
+
+        cb = ALLREDUCE_FN(_cb) if allreduce is not None else ALLREDUCE_FN()
+        rc = self._lib.camsync_calibrate_dist(self._h, _ptr(obj) if V else None, _ptr(img) if V else None, V, P,
+                                              int(n_views_total), W, H, 1 if rational else 0, max_iter, cb, None,
+                                              C.c_void_p(d_work) if d_work else None, _ptr(K), _ptr(dist), _ptr(rvecs),
+                                              _ptr(tvecs), C.byref(rms), C.byref(iters))
+        if failure:
+            raise failure[0]
+        self._check(rc)
+        return rms.value, K, dist, rvecs[:V], tvecs[:V], iters.value
 
     def calib_begin(self, obj, img, rational=False):
         obj = np.ascontiguousarray(obj, dtype=np.float32)

@@ -3,10 +3,16 @@ camera_sync/camera.py:61-63) with the views sharded over ranks.
 
 One process per GPU.  Rank g holds the contiguous share views[lo:hi] (shard_range) and, per LM iteration,
 eliminates its views' extrinsic blocks on the GPU (Schur complement) into the record
-[S (NI x NI) | rhs (NI) | err] — at most 157 doubles — which is summed over ranks with one all-reduce
-(RCCL on GPUs, gloo in the CPU tests).  Every rank then solves the same NI x NI system redundantly and
-back-substitutes its own views, so no parameters are ever broadcast.  A second, scalar all-reduce carries
-the error of the trial step.  The control flow is CvLevMarq::updateAlt's, as in camsync_calibrate.
+[S (NI x NI) | rhs (NI) | err] — at most 157 doubles — which is summed over ranks with one all-reduce.
+Every rank then solves the same NI x NI system redundantly and back-substitutes its own views, so no
+parameters are ever broadcast.  A second, 3-double all-reduce carries the error of the trial step and the
+parameter-change sums.  The control flow is CvLevMarq::updateAlt's.
+
+`calibrate_distributed` runs the loop inside the library (camsync_calibrate_dist: device-resident, one host
+read-back per trial step) and supplies the collective as a callback: torch.distributed.all_reduce — RCCL when the
+process group's backend is "nccl" — on a slice of the torch tensor the library keeps its records in.
+`lm_calibrate` is the same loop on the host over the camsync_calib_* building blocks (any worker object with
+that interface; tests/test_distributed.py runs it over gloo without a GPU).
 """
 import ctypes as C
 import math
@@ -131,22 +137,65 @@ def lm_calibrate(worker, image_size, n_views_total, allreduce, max_iter=30):
     return K, out[4:ni].copy(), rvecs, tvecs, it, err
 
 
-def calibrate_distributed(obj, img, image_size, rational=False, max_iter=30, group=None, device_index=None):
-    """cv.calibrateCamera over torch.distributed.  Every rank passes the FULL obj [V,P,3] / img [V,P,2] (or
-    anything indexable the same way) and works on its own share.  Returns on every rank
-    (rms, K (3,3), dist (5|8), rvecs [V_local,3], tvecs [V_local,3], (lo, hi))."""
+def make_device_allreduce(work, group=None, stats=None):
+    """The camsync_allreduce_fn for torch.distributed: `work` is the float64 device tensor handed to the library
+    as its work buffer; the library asks for slices of it to be summed over the ranks in place.  `stats` (a dict)
+    receives the number of calls and the seconds spent in them."""
+    import time
+
     import torch
     import torch.distributed as dist
 
-    rank, world = (dist.get_rank(group), dist.get_world_size(group)) if dist.is_initialized() else (0, 1)
+    base = work.data_ptr()
+    dev = work.device
+    backend = dist.get_backend(group)
+
+    def allreduce(d_buf, n, stream):
+        t0 = time.perf_counter()
+        off = (d_buf - base) // 8
+        if off < 0 or off + n > work.numel() or (d_buf - base) % 8:
+            raise ValueError("all-reduce request outside the work buffer")
+        view = work[off:off + n]
+        torch.cuda.synchronize(dev)  # the library's stream is not torch's: everything it enqueued must have landed
+        if backend == "nccl":        # RCCL on the device buffer itself
+            dist.all_reduce(view, op=dist.ReduceOp.SUM, group=group)
+        else:                        # gloo (tests): through the host
+            h = view.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+            view.copy_(h)
+        torch.cuda.synchronize(dev)
+        if stats is not None:
+            stats["calls"] = stats.get("calls", 0) + 1
+            stats["seconds"] = stats.get("seconds", 0.0) + time.perf_counter() - t0
+
+    return allreduce
+
+
+def calibrate_distributed(obj, img, image_size, rational=False, max_iter=30, group=None, device_index=None,
+                          return_iters=False, stats=None):
+    """cv.calibrateCamera over torch.distributed.  Every rank passes the FULL obj [V,P,3] / img [V,P,2] (or
+    anything indexable the same way) and works on its own share.  Returns on every rank
+    (rms, K (3,3), dist (5|8), rvecs [V_local,3], tvecs [V_local,3], (lo, hi))[, iters]."""
+    import torch
+    import torch.distributed as dist
+
+    distributed = dist.is_available() and dist.is_initialized()
+    rank, world = (dist.get_rank(group), dist.get_world_size(group)) if distributed else (0, 1)
     V = len(obj)
     lo, hi = shard_range(V, rank, world)
     if device_index is None:
         device_index = torch.cuda.current_device() if torch.cuda.is_available() else 0
     ctx = _hip.Context(32, 32, 1, device=device_index)
-    o = np.asarray(obj[lo:hi], np.float32)
-    P = np.asarray(obj[0]).shape[0]
-    i = np.asarray(img[lo:hi], np.float32).reshape(hi - lo, P, 2)
-    worker = HipCalibWorker(ctx, o.reshape(hi - lo, P, 3), i, rational)
-    K, d, rv, tv, _, err = lm_calibrate(worker, image_size, V, make_allreduce(group), max_iter)
-    return math.sqrt(err / (V * P)), K, d, rv, tv, (lo, hi)
+    try:
+        P = np.asarray(obj[0]).shape[0]
+        o = np.asarray(obj[lo:hi], np.float32).reshape(hi - lo, P, 3)
+        i = np.asarray(img[lo:hi], np.float32).reshape(hi - lo, P, 2)
+        allreduce, d_work, work = None, None, None
+        if distributed:  # (a one-rank group still goes through the collective: that is how the RCCL path is tested on one GPU)
+            work = torch.zeros(_hip.CALIB_WORK_DOUBLES, dtype=torch.float64, device=torch.device("cuda", device_index))
+            allreduce, d_work = make_device_allreduce(work, group, stats), work.data_ptr()
+        rms, K, d, rv, tv, iters = ctx.calibrate_dist(o, i, V, image_size, rational, max_iter, allreduce, d_work)
+    finally:
+        ctx.close()
+    res = (rms, K, d, rv, tv, (lo, hi))
+    return res + (iters,) if return_iters else res

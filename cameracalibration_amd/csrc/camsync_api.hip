@@ -48,9 +48,11 @@ struct camsync_ctx {
     // calibration
     CalibState cal{};
     float *d_calObj = nullptr, *d_calImg = nullptr;
-    double* d_calDelta = nullptr;
+    double* d_calWork = nullptr;   // [CAMSYNC_CALIB_WORK_DOUBLES]: acc | focal sums | trial record | delta | flag (see kW*)
+    double* d_calDelta = nullptr;  // = d_calWork + kWDelta
     double* d_focalRows = nullptr;
-    double* d_focalAcc = nullptr;
+    double* d_focalAcc = nullptr;  // = d_calWork + kWFocal
+    double* h_pin = nullptr;       // pinned host doubles for the small read-backs of the LM loop
     uint8_t* d_calOk = nullptr;
     double* d_calK = nullptr;
     int32_t* d_calNpts = nullptr;
@@ -64,6 +66,11 @@ struct camsync_ctx {
 };
 
 namespace {
+
+// layout of the calibration work buffer (doubles); everything that is summed over ranks lives here, so that a
+// caller-provided buffer (e.g. a torch tensor) can be handed to the collective
+constexpr int kWAcc = 0, kWFocal = 160, kWRec = 168, kWDelta = 176, kWFlag = 190;
+static_assert(kWFlag < CAMSYNC_CALIB_WORK_DOUBLES && 12 * 12 + 12 + 1 <= kWFocal, "work buffer layout");
 
 int fail(camsync_ctx* c, int code, const char* fmt, ...) {
     if (c) {
@@ -413,6 +420,7 @@ int camsync_create(camsync_ctx** out, int device, int max_h, int max_w, int max_
         }
     HIPCHK(c, hipMemcpy(c->d_expTab, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
     for (int i = 0; i <= CAMSYNC_N_STAGES; i++) HIPCHK(c, hipEventCreate(&c->ev[i]));
+    HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_pin), sizeof(double) * 256, hipHostMallocDefault));
     return CAMSYNC_OK;
 }
 
@@ -425,10 +433,11 @@ void camsync_destroy(camsync_ctx* c) {
                     b.outIds, b.outCorners, b.rawCorners, b.outCounts, b.outRejected, b.outRejCounts, c->d_dict, c->d_expTab,
                     c->d_obj, c->d_img, c->d_npts, c->d_K, c->d_dist, c->d_rvec, c->d_tvec, c->d_mae, c->d_rmse, c->d_ok,
                     c->d_anchorIds, c->d_anchorObj, c->d_calObj, c->d_calImg, c->cal.intr, c->cal.ext, c->cal.intrTrial,
-                    c->cal.extTrial, c->cal.viewBlocks, c->cal.partial, c->cal.acc, c->cal.errPartial, c->cal.errOut,
-                    c->d_calDelta, c->d_focalRows, c->d_focalAcc, c->d_calOk, c->d_calK, c->d_calNpts};
+                    c->cal.extTrial, c->cal.viewBlocks, c->cal.partial, c->cal.errPartial,
+                    c->d_calWork, c->d_focalRows, c->d_calOk, c->d_calK, c->d_calNpts};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    if (c->h_pin) (void)hipHostFree(c->h_pin);
     for (int i = 0; i <= CAMSYNC_N_STAGES; i++)
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -858,10 +867,14 @@ int camsync_calib_begin(camsync_ctx* c, const float* obj, const float* img, int 
         return fail(c, CAMSYNC_E_ARG, "calibration needs 4..64 points per view (one wavefront lane per point)");
     HIPCHK(c, hipSetDevice(c->device));
     CalibState& s = c->cal;
-    void* old[] = {c->d_calObj, c->d_calImg, s.intr, s.ext, s.intrTrial, s.extTrial, s.viewBlocks, s.partial, s.acc,
-                   s.errPartial, s.errOut, c->d_calDelta, c->d_focalRows, c->d_focalAcc, c->d_calOk, c->d_calK, c->d_calNpts};
+    void* old[] = {c->d_calObj, c->d_calImg, s.intr, s.ext, s.intrTrial, s.extTrial, s.viewBlocks, s.partial,
+                   s.errPartial, c->d_calWork, c->d_focalRows, c->d_calOk, c->d_calK, c->d_calNpts};
     for (void* p : old)
         if (p) (void)hipFree(p);
+    c->d_calObj = c->d_calImg = nullptr;
+    c->d_calWork = c->d_focalRows = c->d_calK = nullptr;
+    c->d_calOk = nullptr;
+    c->d_calNpts = nullptr;
     c->calReady = false;
     s = CalibState{};
     s.V = V;
@@ -877,12 +890,15 @@ int camsync_calib_begin(camsync_ctx* c, const float* obj, const float* img, int 
     HIPCHK(c, dalloc(&s.extTrial, nv * 6));
     HIPCHK(c, dalloc(&s.viewBlocks, nv * (6 * s.NI + 6)));
     HIPCHK(c, dalloc(&s.partial, nv * L));
-    HIPCHK(c, dalloc(&s.acc, (size_t)L));
+    (void)L;
+    HIPCHK(c, dalloc(&c->d_calWork, (size_t)CAMSYNC_CALIB_WORK_DOUBLES));
+    HIPCHK(c, hipMemset(c->d_calWork, 0, sizeof(double) * CAMSYNC_CALIB_WORK_DOUBLES));
+    s.acc = c->d_calWork + kWAcc;
+    s.errOut = c->d_calWork + kWRec;
+    c->d_calDelta = c->d_calWork + kWDelta;
+    c->d_focalAcc = c->d_calWork + kWFocal;
     HIPCHK(c, dalloc(&s.errPartial, nv));
-    HIPCHK(c, dalloc(&s.errOut, 1));
-    HIPCHK(c, dalloc(&c->d_calDelta, 12));
     HIPCHK(c, dalloc(&c->d_focalRows, nv * 6));
-    HIPCHK(c, dalloc(&c->d_focalAcc, 6));
     HIPCHK(c, dalloc(&c->d_calOk, nv));
     HIPCHK(c, dalloc(&c->d_calK, 9 + 8));
     HIPCHK(c, dalloc(&c->d_calNpts, nv));
@@ -1039,74 +1055,133 @@ int camsync_calib_get(camsync_ctx* c, double intr[12], double* rvecs, double* tv
     return CAMSYNC_OK;
 }
 
-// Single-GPU driver: cvCalibrateCamera2Internal's flow (focal init, per-view
-// extrinsic init, CvLevMarq::updateAlt loop with criteria (COUNT+EPS, max_iter,
-// DBL_EPSILON)).
-int camsync_calibrate(camsync_ctx* c, const float* obj, const float* img, int V, int P, int W, int H, int flags,
-                      int max_iter, double* K, double* dist, double* rvecs, double* tvecs, double* rms, int32_t* iters) {
+// cvCalibrateCamera2Internal's flow (focal init, per-view extrinsic init, CvLevMarq::updateAlt loop with criteria
+// (COUNT+EPS, max_iter, DBL_EPSILON)) with the whole iteration on the device: accumulate -> [sum over ranks] ->
+// solve (one lane) -> back-substitute -> trial error + parameter change -> [sum over ranks] -> ONE read-back of six
+// doubles, on which the host takes the accept / raise-lambda / stop decision.  `ar` is the only thing that differs
+// between one GPU (null) and many.
+static int calibrate_impl(camsync_ctx* c, const float* obj, const float* img, int V, int P, long long Vtotal, int W, int H,
+                          int flags, int max_iter, camsync_allreduce_fn ar, void* user, double* d_work, double* K,
+                          double* dist, double* rvecs, double* tvecs, double* rms, int32_t* iters) {
     if (!c) return CAMSYNC_E_ARG;
-    if (V < 1 || !K || !dist) return fail(c, CAMSYNC_E_ARG, "need at least one view and K/dist outputs");
+    if (V < 0 || Vtotal < 1 || Vtotal < V || !K || !dist) return fail(c, CAMSYNC_E_ARG, "need at least one view overall and K/dist outputs");
     if (max_iter <= 0) max_iter = 30;
     int rc = camsync_calib_begin(c, obj, img, V, P, flags);
     if (rc) return rc;
-    const int NI = c->cal.NI, L = NI * NI + NI + 1;
-    double f6[6];
-    rc = camsync_calib_focal_acc(c, W, H, f6);
+    CalibState& s = c->cal;
+    const int NI = s.NI, L = NI * NI + NI + 1;
+    double* const work = d_work ? d_work : c->d_calWork;
+    if (d_work) {  // the records that cross ranks live in the caller's buffer for this call
+        HIPCHK(c, hipMemsetAsync(work, 0, sizeof(double) * CAMSYNC_CALIB_WORK_DOUBLES, c->stream));
+        s.acc = work + kWAcc;
+        s.errOut = work + kWRec;
+        c->d_calDelta = work + kWDelta;
+        c->d_focalAcc = work + kWFocal;
+    }
+    struct Restore {  // the building-block entry points keep working on the context's own buffer afterwards
+        camsync_ctx* c;
+        ~Restore() {
+            c->cal.acc = c->d_calWork + kWAcc;
+            c->cal.errOut = c->d_calWork + kWRec;
+            c->d_calDelta = c->d_calWork + kWDelta;
+            c->d_focalAcc = c->d_calWork + kWFocal;
+        }
+    } restore{c};
+    auto allreduce = [&](double* p, int n) -> int {
+        if (!ar) return CAMSYNC_OK;
+        const int r = ar(user, p, n, (void*)c->stream);
+        return r ? fail(c, CAMSYNC_E_COMM, "the all-reduce callback failed with %d", r) : CAMSYNC_OK;
+    };
+    double* const hp = c->h_pin;
+
+    // ---- cvInitIntrinsicParams2D: 2x2 normal equations for (1/fx^2, 1/fy^2), summed over ranks ----
+    const double cx0 = (!W) ? 0.5 : (W - 1) * 0.5, cy0 = (!H) ? 0.5 : (H - 1) * 0.5;
+    if (V > 0) launch_calib_focal_rows(s, cx0, cy0, c->d_focalRows, work + kWFocal, c->stream);
+    else HIPCHK(c, hipMemsetAsync(work + kWFocal, 0, sizeof(double) * 6, c->stream));
+    HIPCHK(c, hipGetLastError());
+    rc = allreduce(work + kWFocal, 6);
     if (rc) return rc;
-    // 2x2 normal equations for (1/fx^2, 1/fy^2)
-    const double det = f6[0] * f6[2] - f6[1] * f6[1];
+    HIPCHK(c, hipMemcpyAsync(hp, work + kWFocal, sizeof(double) * 6, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const double det = hp[0] * hp[2] - hp[1] * hp[1];
     if (!(fabs(det) > 0)) return fail(c, CAMSYNC_E_NUMERIC, "focal length initialisation is singular");
-    const double f0 = (f6[3] * f6[2] - f6[4] * f6[1]) / det, f1 = (f6[0] * f6[4] - f6[1] * f6[3]) / det;
-    double intr[12] = {sqrt(fabs(1. / f0)), sqrt(fabs(1. / f1)), (!W) ? 0.5 : (W - 1) * 0.5, (!H) ? 0.5 : (H - 1) * 0.5,
-                       0, 0, 0, 0, 0, 0, 0, 0};
+    const double f0 = (hp[3] * hp[2] - hp[4] * hp[1]) / det, f1 = (hp[0] * hp[4] - hp[1] * hp[3]) / det;
+    double intr[12] = {sqrt(fabs(1. / f0)), sqrt(fabs(1. / f1)), cx0, cy0, 0, 0, 0, 0, 0, 0, 0, 0};
     rc = camsync_calib_set_intrinsics(c, intr, 1);
     if (rc) return rc;
-    std::vector<double> acc(L);
-    double delta[12];
+
+    auto accumulate = [&](int lambdaLg10) -> int {
+        const double lambda = exp(lambdaLg10 * log(10.));
+        if (V > 0) launch_calib_accumulate(s, lambda, c->stream);
+        else HIPCHK(c, hipMemsetAsync(s.acc, 0, sizeof(double) * L, c->stream));
+        return allreduce(s.acc, L);
+    };
+    // one trial step; afterwards hp[0] = error at the trial parameters, hp[1..4] = parameter change sums,
+    // hp[5] = solver flag, hp[6] = error at the current parameters (last entry of the reduced record)
+    auto trial = [&]() -> int {
+        launch_calib_solve(s, work + kWDelta, work + kWFlag, c->stream);
+        launch_calib_backsub(s, work + kWDelta, c->stream);
+        launch_calib_error(s, 1, c->stream);
+        launch_calib_change(s, work + kWRec, c->stream);
+        HIPCHK(c, hipGetLastError());
+        const int r = allreduce(work + kWRec, 3);
+        if (r) return r;
+        HIPCHK(c, hipMemcpyAsync(hp, work + kWRec, sizeof(double) * 5, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(hp + 5, work + kWFlag, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(hp + 6, s.acc + L - 1, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (hp[5] != 0.0) return fail(c, CAMSYNC_E_NUMERIC, "intrinsic block is singular");
+        return CAMSYNC_OK;
+    };
+
     int lambdaLg10 = -3, it = 0;
     double prevErr = 0, errNorm = 0;
     for (;;) {
-        double lambda = exp(lambdaLg10 * log(10.));
-        rc = camsync_calib_accumulate(c, lambda, acc.data(), 0);
+        rc = accumulate(lambdaLg10);
         if (rc) return rc;
-        if (it == 0) prevErr = acc[L - 1];
         for (;;) {
-            rc = camsync_calib_solve(acc.data(), NI, delta);
-            if (rc) return fail(c, rc, "intrinsic block is singular");
-            rc = camsync_calib_step(c, delta, &errNorm);
+            rc = trial();
             if (rc) return rc;
+            if (it == 0) prevErr = hp[6];
+            errNorm = hp[0];
             if (errNorm > prevErr && ++lambdaLg10 <= 16) {
-                lambda = exp(lambdaLg10 * log(10.));
-                rc = camsync_calib_accumulate(c, lambda, acc.data(), 0);
+                rc = accumulate(lambdaLg10);
                 if (rc) return rc;
                 continue;
             }
             break;
         }
         lambdaLg10 = std::max(lambdaLg10 - 1, -16);
-        // relative parameter change ||p - p_prev|| / ||p_prev||
-        std::vector<double> cur((size_t)V * 6 + 12), tri((size_t)V * 6 + 12);
-        HIPCHK(c, hipMemcpy(cur.data(), c->cal.intr, sizeof(double) * 12, hipMemcpyDeviceToHost));
-        HIPCHK(c, hipMemcpy(cur.data() + 12, c->cal.ext, sizeof(double) * V * 6, hipMemcpyDeviceToHost));
-        HIPCHK(c, hipMemcpy(tri.data(), c->cal.intrTrial, sizeof(double) * 12, hipMemcpyDeviceToHost));
-        HIPCHK(c, hipMemcpy(tri.data() + 12, c->cal.extTrial, sizeof(double) * V * 6, hipMemcpyDeviceToHost));
-        double dn = 0, pn = 0;
-        for (size_t i = 0; i < cur.size(); i++) { dn += (tri[i] - cur[i]) * (tri[i] - cur[i]); pn += cur[i] * cur[i]; }
-        rc = camsync_calib_accept(c);
-        if (rc) return rc;
-        const double change = sqrt(dn) / sqrt(pn);
+        // relative parameter change ||p - p_prev|| / ||p_prev|| (extrinsics of all ranks, intrinsics once)
+        const double change = sqrt(hp[1] + hp[3]) / sqrt(hp[2] + hp[4]);
+        launch_calib_accept(s, c->stream);
+        HIPCHK(c, hipGetLastError());
         if (++it >= max_iter || change < 2.220446049250313e-16) break;
         prevErr = errNorm;
     }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     double out[12];
     rc = camsync_calib_get(c, out, rvecs, tvecs);
     if (rc) return rc;
     for (int i = 0; i < 9; i++) K[i] = 0;
     K[0] = out[0]; K[4] = out[1]; K[2] = out[2]; K[5] = out[3]; K[8] = 1;
     for (int i = 0; i < NI - 4; i++) dist[i] = out[4 + i];
-    if (rms) *rms = sqrt(errNorm / ((double)V * P));
+    if (rms) *rms = sqrt(errNorm / ((double)Vtotal * P));
     if (iters) *iters = it;
     return CAMSYNC_OK;
+}
+
+int camsync_calibrate(camsync_ctx* c, const float* obj, const float* img, int V, int P, int W, int H, int flags,
+                      int max_iter, double* K, double* dist, double* rvecs, double* tvecs, double* rms, int32_t* iters) {
+    if (c && V < 1) return fail(c, CAMSYNC_E_ARG, "need at least one view and K/dist outputs");
+    return calibrate_impl(c, obj, img, V, P, V, W, H, flags, max_iter, nullptr, nullptr, nullptr, K, dist, rvecs, tvecs, rms, iters);
+}
+
+int camsync_calibrate_dist(camsync_ctx* c, const float* obj, const float* img, int V_local, int P, int64_t V_total, int W,
+                           int H, int flags, int max_iter, camsync_allreduce_fn allreduce, void* user, double* d_work,
+                           double* K, double* dist, double* rvecs, double* tvecs, double* rms, int32_t* iters) {
+    return calibrate_impl(c, obj, img, V_local, P, (long long)V_total, W, H, flags, max_iter, allreduce, user, d_work, K, dist,
+                          rvecs, tvecs, rms, iters);
 }
 
 /* ---- timers ---- */

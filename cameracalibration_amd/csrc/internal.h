@@ -255,5 +255,7 @@ void launch_calib_backsub(const CalibState& s, const double* di, hipStream_t st)
 void launch_calib_error(const CalibState& s, int useTrial, hipStream_t st);
 void launch_calib_focal_rows(const CalibState& s, double cx, double cy, double* rows, double* acc6, hipStream_t st);
 void launch_calib_accept(const CalibState& s, hipStream_t st);
+void launch_calib_solve(const CalibState& s, double* delta, double* flag, hipStream_t st);
+void launch_calib_change(const CalibState& s, double* rec, hipStream_t st);
 
 }  // namespace camsync

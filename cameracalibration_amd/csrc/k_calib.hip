@@ -251,6 +251,84 @@ __global__ __launch_bounds__(64) void k_calib_focal_rows(CalibState s, double cx
     }
 }
 
+// Solve the reduced NI x NI system S d = rhs on the device (one lane; 12 x 12 at most): Cholesky, with a ridge retry
+// when a pivot vanishes -- the arithmetic of camsync_calib_solve, in the same order.  flag[0] = 1 when both fail.
+template <int NI>
+__global__ void k_calib_solve(const double* __restrict__ acc, double* __restrict__ delta, double* __restrict__ flag) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double A[NI * NI], b[NI];
+    for (int attempt = 0; attempt < 2; attempt++) {
+        double tr = 0;
+        for (int i = 0; i < NI; i++) tr += acc[i * NI + i];
+        for (int i = 0; i < NI * NI; i++) A[i] = acc[i];
+        if (attempt)
+            for (int i = 0; i < NI; i++) A[i * NI + i] += 1e-14 * tr + 1e-300;
+        for (int i = 0; i < NI; i++) b[i] = acc[NI * NI + i];
+        bool ok = true;
+        for (int j = 0; j < NI && ok; j++) {
+            double s = A[j * NI + j];
+            for (int k = 0; k < j; k++) s -= A[j * NI + k] * A[j * NI + k];
+            if (!(s > 0)) { ok = false; break; }
+            const double d = sqrt(s);
+            A[j * NI + j] = d;
+            for (int i = j + 1; i < NI; i++) {
+                double t = A[i * NI + j];
+                for (int k = 0; k < j; k++) t -= A[i * NI + k] * A[j * NI + k];
+                A[i * NI + j] = t / d;
+            }
+        }
+        if (!ok) continue;
+        for (int i = 0; i < NI; i++) {
+            double s = b[i];
+            for (int k = 0; k < i; k++) s -= A[i * NI + k] * b[k];
+            b[i] = s / A[i * NI + i];
+        }
+        for (int i = NI - 1; i >= 0; i--) {
+            double s = b[i];
+            for (int k = i + 1; k < NI; k++) s -= A[k * NI + i] * b[k];
+            b[i] = s / A[i * NI + i];
+        }
+        for (int i = 0; i < NI; i++) delta[i] = b[i];
+        flag[0] = 0.0;
+        return;
+    }
+    for (int i = 0; i < NI; i++) delta[i] = 0.0;
+    flag[0] = 1.0;
+}
+
+// Parameter change of a trial step, for the LM stopping rule ||p_trial - p|| / ||p||: rec[1] = sum over the local
+// extrinsics of (trial - current)^2, rec[2] = sum of current^2 (both to be summed over ranks), rec[3], rec[4] = the same
+// over the intrinsics (replicated on every rank: not to be summed).  rec[0] already holds the trial error.
+__global__ __launch_bounds__(256) void k_calib_change(CalibState s, double* __restrict__ rec) {
+    __shared__ double sd[256], sp[256];
+    double dn = 0, pn = 0;
+    const int n = s.V * 6;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const double c = s.ext[i], d = s.extTrial[i] - c;
+        dn += d * d;
+        pn += c * c;
+    }
+    sd[threadIdx.x] = dn;
+    sp[threadIdx.x] = pn;
+    __syncthreads();
+    for (int d = 128; d >= 1; d >>= 1) {
+        if ((int)threadIdx.x < d) { sd[threadIdx.x] += sd[threadIdx.x + d]; sp[threadIdx.x] += sp[threadIdx.x + d]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        rec[1] = sd[0];
+        rec[2] = sp[0];
+        double di = 0, pi = 0;
+        for (int i = 0; i < 12; i++) {
+            const double c = s.intr[i], d = s.intrTrial[i] - c;
+            di += d * d;
+            pi += c * c;
+        }
+        rec[3] = di;
+        rec[4] = pi;
+    }
+}
+
 __global__ void k_copy_f64(const double* __restrict__ src, double* __restrict__ dst, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = src[i];
@@ -260,7 +338,7 @@ __global__ void k_copy_f64(const double* __restrict__ src, double* __restrict__ 
 
 void launch_calib_accumulate(const CalibState& s, double lambda, hipStream_t st) {
     const int L = s.NI * s.NI + s.NI + 1;
-    const int grid = min(s.V, 256 * 8);
+    const int grid = min(max(s.V, 1), 256 * 8);
     if (s.NI == 9) hipLaunchKernelGGL(k_calib_accumulate<9>, dim3(grid), dim3(64), 0, st, s, lambda);
     else hipLaunchKernelGGL(k_calib_accumulate<12>, dim3(grid), dim3(64), 0, st, s, lambda);
     hipLaunchKernelGGL(k_reduce_views, dim3(L), dim3(256), 0, st, s.partial, s.V, L, s.acc);
@@ -283,6 +361,15 @@ void launch_calib_focal_rows(const CalibState& s, double cx, double cy, double* 
     const int grid = min(max(s.V, 1), 256 * 8);
     hipLaunchKernelGGL(k_calib_focal_rows, dim3(grid), dim3(64), 0, st, s, cx, cy, rows);
     hipLaunchKernelGGL(k_reduce_views, dim3(6), dim3(256), 0, st, rows, s.V, 6, acc6);
+}
+
+void launch_calib_solve(const CalibState& s, double* delta, double* flag, hipStream_t st) {
+    if (s.NI == 9) hipLaunchKernelGGL(k_calib_solve<9>, dim3(1), dim3(1), 0, st, s.acc, delta, flag);
+    else hipLaunchKernelGGL(k_calib_solve<12>, dim3(1), dim3(1), 0, st, s.acc, delta, flag);
+}
+
+void launch_calib_change(const CalibState& s, double* rec, hipStream_t st) {
+    hipLaunchKernelGGL(k_calib_change, dim3(1), dim3(256), 0, st, s, rec);
 }
 
 void launch_calib_accept(const CalibState& s, hipStream_t st) {

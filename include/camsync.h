@@ -30,6 +30,7 @@ extern "C" {
 #define CAMSYNC_E_CAPACITY (-3) /* a per-frame scratch list overflowed */
 #define CAMSYNC_E_NODEVICE (-4) /* no usable GPU */
 #define CAMSYNC_E_NUMERIC (-5)  /* solver failed (reference raises "Could not solve PnP") */
+#define CAMSYNC_E_COMM (-6)     /* the caller's all-reduce callback reported an error */
 
 typedef struct camsync_ctx camsync_ctx;
 
@@ -190,6 +191,26 @@ int camsync_calibrate(camsync_ctx* ctx, const float* obj, const float* img, int 
                       int W, int H, int flags, int max_iter,
                       double* K, double* dist, double* rvecs, double* tvecs,
                       double* rms, int32_t* iters);
+
+/* cv.calibrateCamera (camera.py:61-63) with the views sharded over ranks, one rank per GPU: this rank passes its
+ * V_local views (may be 0) and the global count V_total; the Levenberg-Marquardt loop runs on the device and, per
+ * iteration, sums two small records over the ranks through `allreduce`:
+ *     int allreduce(void* user, double* d_buf, int n, void* hip_stream)
+ * must replace d_buf[0..n) (DEVICE memory) by its sum over all ranks, ordered after the work already enqueued on
+ * hip_stream (a hipStream_t) and before work enqueued on it later, and return 0 -- e.g.
+ * ncclAllReduce(d_buf, d_buf, n, ncclDouble, ncclSum, comm, (hipStream_t)hip_stream) with RCCL, or
+ * torch.distributed.all_reduce on a tensor aliasing the buffer (cameracalibration_amd/calibrate_dist.py).  n is 6
+ * (focal initialisation), ni*ni + ni + 1 <= 157 (normal equations) or 3 (trial error and parameter change).  Every rank
+ * makes the same sequence of calls.  d_work: optional caller-owned device buffer of CAMSYNC_CALIB_WORK_DOUBLES doubles
+ * that then holds every record handed to `allreduce` (so a framework can register it once); NULL = the context's own.
+ * allreduce == NULL is the single-GPU case (camsync_calibrate).  Outputs as camsync_calibrate; rvecs/tvecs are this
+ * rank's V_local views; K, dist, rms, iters are identical on every rank. */
+#define CAMSYNC_CALIB_WORK_DOUBLES 192
+typedef int (*camsync_allreduce_fn)(void* user, double* d_buf, int n, void* hip_stream);
+int camsync_calibrate_dist(camsync_ctx* ctx, const float* obj, const float* img, int V_local, int P, int64_t V_total,
+                           int W, int H, int flags, int max_iter, camsync_allreduce_fn allreduce, void* user,
+                           double* d_work, double* K, double* dist, double* rvecs, double* tvecs,
+                           double* rms, int32_t* iters);
 
 /* Multi-GPU calibration building blocks (one rank per GPU, views sharded
  * contiguously).  The caller owns the LM loop (cvCalibrateCamera2Internal's

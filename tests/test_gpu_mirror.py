@@ -177,3 +177,40 @@ def test_distributed_calibration_two_ranks_on_one_gpu(tmp_path):
     rv = np.concatenate([r["rv"] for r in res]); tv = np.concatenate([r["tv"] for r in res])
     assert np.allclose(rv, rv1, atol=1e-7) and np.allclose(tv, tv1, atol=1e-6)
     assert [tuple(r["span"]) for r in res] == [(0, 16), (16, 31)]
+
+
+def _nccl_rank_main(rank, world, port, V, out_dir):
+    import torch
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    try:
+        from cameracalibration_amd import synth
+        from cameracalibration_amd.calibrate_dist import calibrate_distributed
+
+        obj, img, _, _ = synth.calib_views(V=V, seed=5, rational=True)
+        stats = {}
+        rms, K, d, rv, tv, span, iters = calibrate_distributed(obj, img, (1920, 1080), rational=True, device_index=0,
+                                                               return_iters=True, stats=stats)
+        np.savez(os.path.join(out_dir, "nccl.npz"), rms=rms, K=K, d=d, rv=rv, tv=tv, span=span, iters=iters, calls=stats["calls"])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_distributed_calibration_over_rccl_world_1(tmp_path):
+    """The RCCL leg of the distributed calibration (process group backend "nccl"), as far as one GPU can run it:
+    a one-rank group, every record of every LM iteration all-reduced by RCCL on the device buffer.  The result must be
+    bit-identical to the single-GPU entry point (a one-rank sum changes nothing)."""
+    from cameracalibration_amd import _hip, synth
+
+    V = 40
+    mp.spawn(_nccl_rank_main, args=(1, _free_port(), V, str(tmp_path)), nprocs=1, join=True)
+    r = np.load(tmp_path / "nccl.npz")
+    obj, img, _, _ = synth.calib_views(V=V, seed=5, rational=True)
+    ctx = _hip.Context(32, 32, 1)
+    rms1, K1, d1, rv1, tv1, it1 = ctx.calibrate(obj, img, (1920, 1080), rational=True)
+    assert int(r["iters"]) == it1 and int(r["calls"]) >= 1 + 2 * it1  # focal sums + (record, trial) per iteration
+    assert float(r["rms"]) == rms1
+    assert np.array_equal(r["K"], K1) and np.array_equal(r["d"], d1)
+    assert np.array_equal(r["rv"], rv1) and np.array_equal(r["tv"], tv1)
+    assert abs(rms1 - _oracle.calibrate(obj, img, (1920, 1080), True)[0]) < 1e-6
