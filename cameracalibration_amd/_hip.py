@@ -100,6 +100,7 @@ def load_library() -> C.CDLL:
         lib.camsync_debug_limit_capacity.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32]
         lib.camsync_debug_restore_capacity.argtypes = [vp]
         lib.camsync_pnp_batch.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, vp, vp, vp]
+        lib.camsync_pnp_batch_noalloc.argtypes = lib.camsync_pnp_batch.argtypes
         lib.camsync_ippe_square_batch.argtypes = [vp, vp, vp, i32, vp, vp, i32, i32, vp, vp, vp]
         lib.camsync_detect_pnp_batch.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp, i32, i32,
                                                  i32, vp, vp, vp, vp, vp, vp, vp, vp]
@@ -276,7 +277,9 @@ class Context:
         self._check(self._lib.camsync_debug_restore_capacity(self._h))
 
     # -- pose ----------------------------------------------------------
-    def pnp(self, obj, img, npts, K, dist):
+    def pnp(self, obj, img, npts, K, dist, noalloc=False):
+        """camsync_pnp_batch, or with noalloc=True camsync_pnp_batch_noalloc (no device allocation; B <= 256,
+        B * N <= 16384)."""
         obj = np.ascontiguousarray(obj, dtype=np.float32)
         img = np.ascontiguousarray(img, dtype=np.float32)
         B, N = obj.shape[0], obj.shape[1]
@@ -284,8 +287,9 @@ class Context:
         K, d, per_frame = _cam(K, dist, B)
         rvec = np.zeros((B, 3)); tvec = np.zeros((B, 3)); ok = np.zeros(B, np.uint8)
         mae = np.zeros(B); rmse = np.zeros(B)
-        self._check(self._lib.camsync_pnp_batch(self._h, _ptr(obj), _ptr(img), _ptr(npts), B, N, _ptr(K), _ptr(d),
-                                                d.shape[1], per_frame, _ptr(rvec), _ptr(tvec), _ptr(ok), _ptr(mae), _ptr(rmse)))
+        fn = self._lib.camsync_pnp_batch_noalloc if noalloc else self._lib.camsync_pnp_batch
+        self._check(fn(self._h, _ptr(obj), _ptr(img), _ptr(npts), B, N, _ptr(K), _ptr(d),
+                       d.shape[1], per_frame, _ptr(rvec), _ptr(tvec), _ptr(ok), _ptr(mae), _ptr(rmse)))
         return rvec, tvec, ok, mae, rmse
 
     def ippe_square(self, corners, size, K, dist):

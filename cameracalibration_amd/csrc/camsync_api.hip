@@ -10,6 +10,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <algorithm>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -22,6 +23,7 @@ struct camsync_ctx {
     camsync_params params;
     int dictN = 0, markerSize = 4, maxCorrectionBits = 1;
     std::string err;
+    unsigned char* naScratch = nullptr;  // this GPU's copy of the no-allocation scratch array (see scratch_for_device)
     unsigned int allocContourCap = 0, allocPoolCap = 0, allocTaskCap = 0;  // set once camsync_debug_limit_capacity lowered them
 
     // device scratch
@@ -65,7 +67,48 @@ struct camsync_ctx {
     int64_t launches[CAMSYNC_N_STAGES] = {};
 };
 
+// ---- scratch of the entry point that allocates nothing (camsync_pnp_batch_noalloc) ------------------------------
+// camsync_pnp_batch stages its host inputs and its results in device buffers that it (re)allocates when a batch is
+// larger than any before.  The no-allocation variant stages them in this file-scope device array instead: every GPU
+// the library runs on holds one copy (400 KiB) until the process ends.  In host code the array's NAME is only a
+// handle; its device address is resolved once per device, with that device current, by hipGetSymbolAddress
+// (scratch_for_device below, called from camsync_create), and only that pointer is ever passed to copies and kernels.
 namespace {
+constexpr size_t kNaMaxFrames = CAMSYNC_NOALLOC_MAX_FRAMES, kNaMaxPoints = CAMSYNC_NOALLOC_MAX_POINTS;
+constexpr size_t kNaObj = 0;                                        // f32 [points, 3]
+constexpr size_t kNaImg = kNaObj + kNaMaxPoints * 3 * 4;            // f32 [points, 2]
+constexpr size_t kNaK = kNaImg + kNaMaxPoints * 2 * 4;              // f64 [frames, 9]
+constexpr size_t kNaDist = kNaK + kNaMaxFrames * 9 * 8;             // f64 [frames, 8]
+constexpr size_t kNaRvec = kNaDist + kNaMaxFrames * 8 * 8;          // f64 [frames, 3]
+constexpr size_t kNaTvec = kNaRvec + kNaMaxFrames * 3 * 8;          // f64 [frames, 3]
+constexpr size_t kNaMae = kNaTvec + kNaMaxFrames * 3 * 8;           // f64 [frames]
+constexpr size_t kNaRmse = kNaMae + kNaMaxFrames * 8;               // f64 [frames]
+constexpr size_t kNaNpts = kNaRmse + kNaMaxFrames * 8;              // i32 [frames]
+constexpr size_t kNaOk = kNaNpts + kNaMaxFrames * 4;                // u8  [frames]
+constexpr size_t kNaBytes = ((kNaOk + kNaMaxFrames + 255) / 256) * 256;
+static_assert(kNaImg % 8 == 0 && kNaK % 8 == 0 && kNaNpts % 8 == 0, "scratch fields are 8-byte aligned");
+}  // namespace
+static __device__ __align__(256) unsigned char scratch[kNaBytes];
+
+namespace {
+
+constexpr int kMaxDevices = 64;
+unsigned char* g_scratchPtr[kMaxDevices] = {};  // device address of `scratch` on each GPU (each GPU has its own copy)
+std::mutex g_scratchMutex;
+
+// Resolve the address of this device's copy of `scratch` (the device must be current).  Returns null on failure.
+unsigned char* scratch_for_device(int device, hipError_t* err) {
+    *err = hipSuccess;
+    if (device < 0 || device >= kMaxDevices) { *err = hipErrorInvalidDevice; return nullptr; }
+    std::lock_guard<std::mutex> lock(g_scratchMutex);
+    if (!g_scratchPtr[device]) {
+        void* p = nullptr;
+        *err = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (*err != hipSuccess || !p) return nullptr;
+        g_scratchPtr[device] = static_cast<unsigned char*>(p);
+    }
+    return g_scratchPtr[device];
+}
 
 // layout of the calibration work buffer (doubles); everything that is summed over ranks lives here, so that a
 // caller-provided buffer (e.g. a torch tensor) can be handed to the collective
@@ -365,6 +408,11 @@ int camsync_create(camsync_ctx** out, int device, int max_h, int max_w, int max_
     c->maxB = max_batch;
     camsync_default_params(&c->params);
     HIPCHK(c, hipSetDevice(device));
+    {
+        hipError_t e = hipSuccess;
+        c->naScratch = scratch_for_device(device, &e);
+        if (!c->naScratch) return fail(c, CAMSYNC_E_HIP, "hipGetSymbolAddress(scratch) on device %d: %s", device, hipGetErrorString(e));
+    }
     HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     const size_t px = (size_t)max_h * max_w, B = (size_t)max_batch;
     DetBuffers& b = c->buf;
@@ -833,6 +881,53 @@ int camsync_pnp_batch(camsync_ctx* c, const float* obj, const float* img, const 
         float ms = 0;
         if (hipEventElapsedTime(&ms, c->ev[7], c->ev[8]) == hipSuccess) { c->ms[7] += ms; c->launches[7]++; }
     }
+    return CAMSYNC_OK;
+}
+
+int camsync_pnp_batch_noalloc(camsync_ctx* c, const float* obj, const float* img, const int32_t* npts, int B, int N,
+                              const double* K, const double* dist, int ndist, int per_frame_cam, double* rvec,
+                              double* tvec, uint8_t* ok, double* mae, double* rmse) {
+    if (!c) return CAMSYNC_E_ARG;
+    if (!obj || !img || !npts || !K || !rvec || !tvec || !ok || B <= 0) return fail(c, CAMSYNC_E_ARG, "missing argument");
+    if (N < 4 || N > 64) return fail(c, CAMSYNC_E_ARG, "N must be 4..64 points per frame (one wavefront lane per point)");
+    if (ndist < 0 || ndist > 8 || (ndist > 0 && !dist)) return fail(c, CAMSYNC_E_ARG, "ndist must be 0..8");
+    if ((size_t)B > kNaMaxFrames || (size_t)B * (size_t)N > kNaMaxPoints)
+        return fail(c, CAMSYNC_E_CAPACITY,
+                    "camsync_pnp_batch_noalloc handles at most %d frames and %d points (B * N) per call, got B = %d, N = %d; "
+                    "use camsync_pnp_batch", CAMSYNC_NOALLOC_MAX_FRAMES, CAMSYNC_NOALLOC_MAX_POINTS, B, N);
+    HIPCHK(c, hipSetDevice(c->device));
+    unsigned char* const sp = c->naScratch;  // device address of this GPU's scratch array, never the symbol itself
+    if (!sp) return fail(c, CAMSYNC_E_HIP, "no scratch address for device %d", c->device);
+    float* d_obj = reinterpret_cast<float*>(sp + kNaObj);
+    float* d_img = reinterpret_cast<float*>(sp + kNaImg);
+    double* d_K = reinterpret_cast<double*>(sp + kNaK);
+    double* d_dist = reinterpret_cast<double*>(sp + kNaDist);
+    double* d_rvec = reinterpret_cast<double*>(sp + kNaRvec);
+    double* d_tvec = reinterpret_cast<double*>(sp + kNaTvec);
+    double* d_mae = reinterpret_cast<double*>(sp + kNaMae);
+    double* d_rmse = reinterpret_cast<double*>(sp + kNaRmse);
+    int32_t* d_npts = reinterpret_cast<int32_t*>(sp + kNaNpts);
+    uint8_t* d_ok = sp + kNaOk;
+    const size_t kc = per_frame_cam ? (size_t)B : 1;
+    // every field the kernel reads is overwritten for the B frames of this call, and it writes every output of those
+    // frames: nothing has to start at zero, and what an earlier (larger) call left behind is never read
+    HIPCHK(c, hipMemcpyAsync(d_obj, obj, sizeof(float) * 3 * N * B, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_img, img, sizeof(float) * 2 * N * B, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_npts, npts, sizeof(int32_t) * B, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_K, K, sizeof(double) * 9 * kc, hipMemcpyHostToDevice, c->stream));
+    if (ndist) HIPCHK(c, hipMemcpyAsync(d_dist, dist, sizeof(double) * ndist * kc, hipMemcpyHostToDevice, c->stream));
+    PnpArgs a{};
+    a.obj = d_obj; a.img = d_img; a.npts = d_npts; a.B = B; a.N = N;
+    a.K = d_K; a.dist = d_dist; a.ndist = ndist; a.perFrameCam = per_frame_cam; a.refine = 1;
+    a.rvec = d_rvec; a.tvec = d_tvec; a.ok = d_ok; a.mae = d_mae; a.rmse = d_rmse;
+    launch_pnp(a, c->stream);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(rvec, d_rvec, sizeof(double) * 3 * B, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(tvec, d_tvec, sizeof(double) * 3 * B, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(ok, d_ok, B, hipMemcpyDeviceToHost, c->stream));
+    if (mae) HIPCHK(c, hipMemcpyAsync(mae, d_mae, sizeof(double) * B, hipMemcpyDeviceToHost, c->stream));
+    if (rmse) HIPCHK(c, hipMemcpyAsync(rmse, d_rmse, sizeof(double) * B, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return CAMSYNC_OK;
 }
 

@@ -152,6 +152,20 @@ int camsync_pnp_batch(camsync_ctx* ctx, const float* obj, const float* img, cons
                       int per_frame_cam, double* rvec, double* tvec, uint8_t* ok,
                       double* mae, double* rmse);
 
+/* camsync_pnp_batch for callers that must not allocate device memory (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments and results as
+ * camsync_pnp_batch, but the inputs and results are staged in a fixed device array that lives in the library image
+ * (about 400 KiB per GPU, held until the process ends) instead of buffers that grow with the batch, so the call makes
+ * no hipMalloc / hipFree.  Limits: B <= CAMSYNC_NOALLOC_MAX_FRAMES and B * N <= CAMSYNC_NOALLOC_MAX_POINTS; larger
+ * batches fail with CAMSYNC_E_CAPACITY (use camsync_pnp_batch).  All contexts of one GPU share that array: calls that
+ * overlap in time on the same GPU race (serialise them); calls on different GPUs are independent. */
+#define CAMSYNC_NOALLOC_MAX_FRAMES 256
+#define CAMSYNC_NOALLOC_MAX_POINTS 16384
+int camsync_pnp_batch_noalloc(camsync_ctx* ctx, const float* obj, const float* img, const int32_t* npts,
+                              int B, int N, const double* K, const double* dist, int ndist,
+                              int per_frame_cam, double* rvec, double* tvec, uint8_t* ok,
+                              double* mae, double* rmse);
+
 /* cv.solvePnP(SOLVEPNP_IPPE_SQUARE) for B squares (aruco.py:97-117 inside
  * estimate_pose_single_markers).  corners f32 [B,4,2] (TL,TR,BR,BL),
  * size f64 [B], K/dist as above. */
