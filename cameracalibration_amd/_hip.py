@@ -94,6 +94,7 @@ def load_library() -> C.CDLL:
         lib.camsync_detect_batch.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, i32, vp, vp]
         lib.camsync_debug_counts.argtypes = [vp, i32, vp]
         lib.camsync_debug_lists.argtypes = [vp, vp, vp]
+        lib.camsync_debug_planes.argtypes = [vp, i32, i32, vp]
         lib.camsync_debug_quads.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp]
         lib.camsync_debug_contours.argtypes = [vp, i32, i32, vp, vp, vp, vp]
         lib.camsync_debug_points.argtypes = [vp, i32, i32, vp]
@@ -244,6 +245,12 @@ class Context:
         used = np.zeros(8, np.uint32); cap = np.zeros(8, np.uint32)
         self._check(self._lib.camsync_debug_lists(self._h, _ptr(used), _ptr(cap)))
         return {n: (int(u), int(k)) for n, u, k in zip(self.LIST_NAMES, used, cap)}
+
+    def debug_planes(self, frame, scale, H, W):
+        """Threshold bits [H,W] (0/1) of `frame` at `scale` from the last detection chunk."""
+        out = np.zeros((H, W), np.uint8)
+        self._check(self._lib.camsync_debug_planes(self._h, frame, scale, _ptr(out)))
+        return out
 
     def debug_quads(self, frame=0, cap=1024):
         c = np.zeros((cap, 4, 2), np.float32)

@@ -766,6 +766,20 @@ int camsync_debug_counts(camsync_ctx* c, int frame, int32_t out[8]) {
     return CAMSYNC_OK;
 }
 
+int camsync_debug_planes(camsync_ctx* c, int frame, int scale, uint8_t* out_bits) {
+    if (!c || !out_bits || frame < 0 || frame >= c->lastB) return CAMSYNC_E_ARG;
+    const DetCfg cfg = make_cfg(c, c->lastH, c->lastW);
+    if (scale < 0 || scale >= cfg.nScales) return fail(c, CAMSYNC_E_ARG, "scale %d outside 0..%d", scale, cfg.nScales - 1);
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t per = plane_words(cfg.H, cfg.WS);
+    std::vector<uint32_t> h(per);
+    HIPCHK(c, hipMemcpy(h.data(), c->buf.planes + ((size_t)frame * cfg.nScales + scale) * per, per * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    for (int y = 0; y < cfg.H; y++)
+        for (int x = 0; x < cfg.W; x++)
+            out_bits[(size_t)y * cfg.W + x] = (uint8_t)((h[plane_word_index(cfg.WS, x >> 5, y)] >> (x & 31)) & 1u);
+    return CAMSYNC_OK;
+}
+
 int camsync_debug_lists(camsync_ctx* c, uint32_t used[8], uint32_t cap[8]) {
     if (!c || !used || !cap) return CAMSYNC_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));

@@ -125,6 +125,10 @@ int camsync_debug_counts(camsync_ctx* ctx, int frame, int32_t out[8]);
  * chunks (128 bytes per 256 steps of a long border), [6] copy tasks, [7] borders handed to the tail pass.  The
  * counters include the blocks the border-follower waves reserve and leave partly unused. */
 int camsync_debug_lists(camsync_ctx* ctx, uint32_t used[8], uint32_t cap[8]);
+/* The threshold image of `frame` at `scale` as the detection pipeline of the last chunk produced it (one bit per
+ * pixel on the device; here one byte per pixel, 0 or 1, [H,W]): cv.adaptiveThreshold(MEAN_C, BINARY_INV) with the
+ * image's outermost pixel frame cleared, which is what findContours sees. */
+int camsync_debug_planes(camsync_ctx* ctx, int frame, int scale, uint8_t* out_bits);
 int camsync_debug_quads(camsync_ctx* ctx, int frame, int max_quads, float* corners,
                         int32_t* scale, int32_t* scan_key, int32_t* contour_len,
                         int32_t* id, int32_t* rot);

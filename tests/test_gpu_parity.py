@@ -260,3 +260,32 @@ def test_calibrate_vs_oracle(ctx, rational):
     assert rms < 0.45
     assert np.allclose(K, oK, rtol=1e-5)
     assert abs(K[0, 0] - 1400) < 15 and abs(K[1, 1] - 1400) < 15
+
+
+@pytest.mark.parametrize("size", ["1080p", "4k"])
+@pytest.mark.parametrize("channels", [3, 1])
+def test_pipeline_threshold_planes_bit_exact(size, channels):
+    """The kernel instances the detection pipeline (and bench.py) actually run -- k_gray_thresh3 with the width
+    compiled in, 3-channel (MODE 1) and 1-channel (MODE 2) input, no gray image written -- compared bit for bit with
+    the oracle's adaptiveThreshold at the three window sizes on full 1080p and 4K frames.  (camsync_gray_threshold,
+    which the other threshold tests use, runs the run-time-parameter instance.)"""
+    from cameracalibration_amd import _hip, synth
+    if size == "1080p":
+        K, _ = _data.calibration("Logitec_robot_1920-1080_10.npz")
+        frames = np.stack([synth.v1_frame(70 + i, K, ss=2, device="cuda")[0].cpu().numpy() for i in range(2)])
+    else:
+        K4 = np.array([[2800.0, 0, 1920.0], [0, 2800.0, 1080.0], [0, 0, 1.0]])
+        frames = np.stack([synth.grid_frame(20 + i, K4, ss=2, device="cuda")[0].cpu().numpy() for i in range(2)])
+    if channels == 1:
+        frames = np.stack([orc.bgr2gray(f) for f in frames])[..., None]
+    B, H, W = frames.shape[:3]
+    c = _hip.Context(H, W, B)
+    c.detect(frames)
+    for b in range(B):
+        gray = frames[b, :, :, 0] if channels == 1 else orc.bgr2gray(frames[b])
+        for s, win in enumerate((3, 13, 23)):
+            want = (orc.adaptive_threshold(gray, win) > 0).astype(np.uint8)
+            want[0, :] = want[-1, :] = 0
+            want[:, 0] = want[:, -1] = 0
+            got = c.debug_planes(b, s, H, W)
+            assert np.array_equal(got, want), (b, win, int((got != want).sum()))
