@@ -95,6 +95,7 @@ def load_library() -> C.CDLL:
         lib.camsync_debug_counts.argtypes = [vp, i32, vp]
         lib.camsync_debug_lists.argtypes = [vp, vp, vp]
         lib.camsync_debug_planes.argtypes = [vp, i32, i32, vp]
+        lib.camsync_debug_starts.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
         lib.camsync_debug_quads.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp]
         lib.camsync_debug_contours.argtypes = [vp, i32, i32, vp, vp, vp, vp]
         lib.camsync_debug_points.argtypes = [vp, i32, i32, vp]
@@ -251,6 +252,17 @@ class Context:
         out = np.zeros((H, W), np.uint8)
         self._check(self._lib.camsync_debug_planes(self._h, frame, scale, _ptr(out)))
         return out
+
+    def debug_starts(self, frames, cap=1 << 22):
+        """Contour-start candidates of `frames` (threshold + start stages only): sorted uint64 array, see camsync.h."""
+        f = self._frames(frames)
+        B, H, W, Cn = f.shape
+        out = np.zeros(cap, np.uint64)
+        n = self._lib.camsync_debug_starts(self._h, _ptr(f), B, H, W, Cn, cap, _ptr(out))
+        if n < 0:
+            self._check(n)
+        assert n <= cap
+        return np.sort(out[:n])
 
     def debug_quads(self, frame=0, cap=1024):
         c = np.zeros((cap, 4, 2), np.float32)

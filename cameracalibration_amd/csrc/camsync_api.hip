@@ -766,6 +766,39 @@ int camsync_debug_counts(camsync_ctx* c, int frame, int32_t out[8]) {
     return CAMSYNC_OK;
 }
 
+int camsync_debug_starts(camsync_ctx* c, const uint8_t* frames, int B, int H, int W, int C, int max_starts, uint64_t* out) {
+    int rc = check_frame_args(c, frames, B, H, W, C);
+    if (rc) return rc;
+    if (B > c->maxB || max_starts < 0 || (max_starts > 0 && !out)) return fail(c, CAMSYNC_E_ARG, "batch larger than the context's chunk, or no output");
+    HIPCHK(c, hipSetDevice(c->device));
+    rc = ensure_staging(c);
+    if (rc) return rc;
+    const DetCfg cfg = make_cfg(c, H, W);
+    rc = ensure_planes(c, cfg.nScales);
+    if (rc) return rc;
+    if (!gray_thresh_is_fused(cfg)) {
+        rc = ensure_gray(c);
+        if (rc) return rc;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_in, frames, (size_t)B * H * W * C, hipMemcpyHostToDevice, c->stream));
+    DetBuffers b = c->buf;
+    b.in = c->d_in;
+    b.bin = nullptr;
+    if (gray_thresh_is_fused(cfg)) b.gray = nullptr;
+    HIPCHK(c, hipMemsetAsync(b.counters, 0, sizeof(Counters), c->stream));
+    launch_gray_thresh(cfg, b, B, C, c->stream);
+    launch_contour_starts(cfg, b, B, c->stream);
+    HIPCHK(c, hipGetLastError());
+    Counters h;
+    HIPCHK(c, hipMemcpyAsync(&h, b.counters, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const unsigned int n = std::min(h.nCand, b.candCap);
+    const unsigned int m = std::min<unsigned int>(n, (unsigned int)max_starts);
+    if (m) HIPCHK(c, hipMemcpy(out, b.cand, sizeof(uint64_t) * m, hipMemcpyDeviceToHost));
+    c->lastB = B; c->lastH = H; c->lastW = W;
+    return (int)std::min<unsigned int>(h.nCand, 0x7FFFFFFFu);
+}
+
 int camsync_debug_planes(camsync_ctx* c, int frame, int scale, uint8_t* out_bits) {
     if (!c || !out_bits || frame < 0 || frame >= c->lastB) return CAMSYNC_E_ARG;
     const DetCfg cfg = make_cfg(c, c->lastH, c->lastW);

@@ -38,6 +38,8 @@
 // The traces only read the image, so they are independent of each other.
 #include "internal.h"
 
+#include <algorithm>
+
 namespace camsync {
 
 namespace {
@@ -54,25 +56,28 @@ __device__ __forceinline__ uint32_t fill_down(uint32_t seed, uint32_t run) {
 constexpr int kStage = 512;  // starts staged per wavefront before a flush
 
 // word (xw, y) of a block-linear plane, zero outside the plane
-__device__ __forceinline__ uint32_t pw(const uint32_t* __restrict__ plane, int WS, int H, int xw, int y) {
+__device__ __forceinline__ uint32_t pw_at(const uint32_t* __restrict__ plane, int WS, int H, int xw, int y) {
     if (xw < 0 || xw >= WS || y < 0 || y >= H) return 0u;
     return plane[plane_word_index(WS, xw, y)];
 }
 
-// A wavefront handles two horizontally adjacent plane blocks per round: lane = (block, row), so the centre
-// words are two whole cache lines, the rows above come from the neighbouring lanes, and nothing is divided
-// per thread.  Waves own contiguous ranges of block pairs and stage their starts in a private LDS list
-// (no workgroup barriers); the global list is appended to with one atomic per flush.
-__global__ __launch_bounds__(256) void k_contour_starts(const uint32_t* __restrict__ planes, DetCfg cfg, int B,
-                                                        uint64_t* __restrict__ cand, unsigned int candCap,
-                                                        Counters* __restrict__ ctr) {
-    __shared__ uint64_t s_list[4][kStage];
+// A lane owns one column of plane blocks (32 pixels wide) and walks down it, eight rows (two 16-byte loads) at a
+// time; a wavefront is 62 such columns side by side plus one halo column at either end, over a band of rows of one
+// plane.  The rows above and below a row are then the lane's own registers from the previous / next step, and only
+// the one bit that crosses a word boundary comes from the neighbouring lane (DPP wave shifts): about twenty vector
+// instructions per 32 pixels when nothing starts in them.  Two groups of rows are loaded ahead of the one being
+// processed.  Starts are staged in LDS and appended to the global list with one atomic per flush.
+constexpr int kStartCols = 62;  // useful block columns per wavefront (lanes 1..62)
+
+__global__ __launch_bounds__(64) void k_contour_starts(const uint32_t* __restrict__ planes, DetCfg cfg, int B, int bands,
+                                                       int bandGroups, uint64_t* __restrict__ cand, unsigned int candCap,
+                                                       Counters* __restrict__ ctr) {
+    __shared__ uint64_t stage[kStage];
     const int H = cfg.H, WS = cfg.WS, S = cfg.nScales, W = cfg.W, HB = plane_hb(H);
-    const int WP = (WS + 1) >> 1;
+    const int colGroups = (WS + kStartCols - 1) / kStartCols;
     const size_t perPlane = plane_words(H, WS);
     const bool dropIsolated = cfg.minPerim > 1;
-    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    uint64_t* const stage = s_list[wv];
+    const int lane = threadIdx.x;
     unsigned int staged = 0;  // uniform
 
     auto flush = [&]() {
@@ -89,110 +94,64 @@ __global__ __launch_bounds__(256) void k_contour_starts(const uint32_t* __restri
         }
     };
 
-    const unsigned long long units = (unsigned long long)B * S * HB * WP;
-    const unsigned long long nw = (unsigned long long)gridDim.x * 4, w = (unsigned long long)blockIdx.x * 4 + wv;
-    unsigned long long u = units * w / nw;
-    const unsigned long long uEnd = units * (w + 1) / nw;
-    // decode once, then count up
-    // (wave-uniform values: kept in scalar registers)
-    unsigned long long t = u / WP;
-    int p = __builtin_amdgcn_readfirstlane((int)(u % WP));
-    int by = __builtin_amdgcn_readfirstlane((int)(t % HB));
-    unsigned int fs = (unsigned int)__builtin_amdgcn_readfirstlane((int)(t / HB));
-    unsigned int left = (unsigned int)__builtin_amdgcn_readfirstlane((int)(uEnd - u));        // units of this wave
-    const unsigned int avail = (unsigned int)__builtin_amdgcn_readfirstlane((int)(units - u < 0x7FFFFFFFull ? units - u : 0x7FFFFFFFull));  // units up to the end
-    auto advance = [&](int& pp, int& bby, unsigned int& ffs) {
-        if (++pp == WP) {
-            pp = 0;
-            if (++bby == HB) {
-                bby = 0;
-                ffs++;
-            }
+    // which band of which column group of which plane (uniform)
+    unsigned int u = blockIdx.x;
+    const int band = (int)(u % (unsigned)bands);
+    u /= (unsigned)bands;
+    const int cg = (int)(u % (unsigned)colGroups);
+    const unsigned int fs = u / (unsigned)colGroups;  // frame * S + scale
+    if (fs >= (unsigned)B * (unsigned)S) return;
+    const int totalGroups = HB * 4;  // groups of eight rows in a plane
+    const int g0 = band * bandGroups, g1 = min(totalGroups, g0 + bandGroups);
+    if (g0 >= g1) return;
+    const int bx = cg * kStartCols - 1 + lane;
+    const bool inPlane = bx >= 0 && bx < WS;
+    const bool mine = inPlane && lane >= 1 && lane <= kStartCols;  // halo lanes only lend their edge bits
+    const uint32_t om = mine ? 0xFFFFFFFFu : 0u;
+    // pixels beyond the image width are padding: nothing starts there
+    const uint32_t hm = !mine ? 0u : ((bx + 1) * 32 > W ? (1u << (W - bx * 32)) - 1u : 0xFFFFFFFFu);
+    const uint32_t* const plane = planes + (size_t)fs * perPlane;
+    const uint32_t f = fs / (unsigned int)S, sc = fs % (unsigned int)S;
+
+    // eight consecutive rows of this lane's column, starting at row 8 g (zero outside the plane)
+    struct Rows { uint4 a, b; };
+    auto load_rows = [&](int g) {
+        Rows r;
+        r.a = make_uint4(0, 0, 0, 0);
+        r.b = make_uint4(0, 0, 0, 0);
+        if (inPlane && g < totalGroups) {
+            const uint4* src = reinterpret_cast<const uint4*>(plane + ((size_t)(g >> 2) * WS + bx) * 32 + (g & 3) * 8);
+            r.a = src[0];
+            r.b = src[1];
         }
-    };
-    // The words of a round are loaded one round ahead, so a wave always has a round's loads in flight.  A lane
-    // loads only its own word (and lanes 0/32 and 31/63 the rows just above and below the block pair); the words
-    // of the blocks to the left and right -- of which only the adjacent bit matters -- come from the other half
-    // of the wave, from the round before (kept in registers) and from the round after (already loaded).
-    struct Words { uint32_t c, n, s; };
-    const Words kZero = {0u, 0u, 0u};
-    const int r = lane & 31;
-    const bool half0 = lane < 32;
-    auto load_unit = [&](int pp, int bby, unsigned int ffs) {
-        Words q = kZero;
-        const int bx = 2 * pp + (lane >> 5);
-        const uint32_t* plane = planes + (size_t)ffs * perPlane;
-        if (bx < WS) {
-            const size_t ci = ((size_t)bby * WS + bx) * 32 + r;
-            q.c = plane[ci];
-            // the row above the first row of a block lives in the block above, the row below the last in the block below
-            if (r == 0 && bby > 0) q.n = plane[((size_t)(bby - 1) * WS + bx) * 32 + 31];
-            if (r == 31 && bby + 1 < HB) q.s = plane[((size_t)(bby + 1) * WS + bx) * 32];
-        }
-        return q;
-    };
-    // the same words as the other half of the wave holds them (lane ^ 32)
-    auto other_half = [&](const Words& q) {
-        Words o;
-        const auto a = __builtin_amdgcn_permlane32_swap(q.c, q.c, false, false);
-        const auto b = __builtin_amdgcn_permlane32_swap(q.n, q.n, false, false);
-        const auto d = __builtin_amdgcn_permlane32_swap(q.s, q.s, false, false);
-        o.c = half0 ? a[1] : a[0];
-        o.n = half0 ? b[1] : b[0];
-        o.s = half0 ? d[1] : d[0];
-        return o;
+        return r;
     };
     auto lane_before = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false); };
     auto lane_after = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false); };
-    // Two rounds of loads are in flight: the unit after this one is needed in this round (its left block is the
-    // right neighbour of this unit's right block), the one after that is requested now.
-    Words cur = kZero, curO = kZero, prevO = kZero, nxt = kZero;
-    int np = p, nby = by;
-    unsigned int nfs = fs;
-    advance(np, nby, nfs);
-    if (left) {
-        cur = load_unit(p, by, fs);
-        if (avail > 1) nxt = load_unit(np, nby, nfs);
-        if (p > 0) prevO = other_half(load_unit(p - 1, by, fs));
-        curO = other_half(cur);
-    }
-    for (unsigned int it = 0; it < left; it++) {
-        int np2 = np, nby2 = nby;
-        unsigned int nfs2 = nfs;
-        advance(np2, nby2, nfs2);
-        Words nxt2 = kZero;
-        if (it + 2 < avail) nxt2 = load_unit(np2, nby2, nfs2);
-        const Words nxtO = other_half(nxt);
-        const Words rightO = np != 0 ? nxtO : kZero;  // a new row of blocks starts: nothing to the right
+    // a row's pixels shifted by one: bit i = the pixel to the west / east of pixel i
+    auto west_of = [&](uint32_t c) { return __funnelshift_l(lane_before(c), c, 1); };   // (c << 1) | (left word >> 31)
+    auto east_of = [&](uint32_t c) { return __funnelshift_r(c, lane_after(c), 1); };    // (c >> 1) | (right word << 31)
 
-        const int bx = 2 * p + (lane >> 5), y = by * 32 + r;
-        const uint32_t* plane = planes + (size_t)fs * perPlane;
-        const uint32_t c = cur.c;
-        const uint32_t cl = half0 ? prevO.c : curO.c, cr = half0 ? curO.c : rightO.c;
-        // the row above: the lane before, except for the first row of a block
-        uint32_t n = lane_before(c), nl = lane_before(cl), nr = lane_before(cr);
-        if (r == 0) {
-            n = cur.n;
-            nl = half0 ? prevO.n : curO.n;
-            nr = half0 ? curO.n : rightO.n;
-        }
-        // the row below likewise (only the isolated-pixel test looks at it)
-        uint32_t sd = lane_after(c), sl = lane_after(cl), sr = lane_after(cr);
-        if (r == 31) {
-            sd = cur.s;
-            sl = half0 ? prevO.s : curO.s;
-            sr = half0 ? curO.s : rightO.s;
-        }
-        uint32_t outer = 0, hole = 0;
-        if ((c | n) && y <= H - 2) {  // nothing can start in an all-zero word under an all-zero word
-            const uint32_t wst = (c << 1) | (cl >> 31);
-            const uint32_t nw2 = (n << 1) | (nl >> 31);
-            const uint32_t ne = (n >> 1) | (nr << 31);
-            const uint32_t above = n | nw2 | ne;  // some foreground 8-adjacent in the row above
-            outer = c & ~wst & ~above;
-            hole = ~c & wst & n;
-            if ((bx + 1) * 32 > W) hole &= (1u << (W - bx * 32)) - 1u;  // pixels beyond the image width are padding
-            if (outer) {
+    // the row above the band's first row (zero above the plane), and its shifted copies
+    uint32_t pc = 0;
+    if (g0 > 0 && inPlane) pc = plane[plane_word_index(WS, bx, 8 * g0 - 1)];
+    uint32_t pw = west_of(pc), pe = east_of(pc);
+    Rows cur = load_rows(g0), nx1 = load_rows(g0 + 1), nx2 = load_rows(g0 + 2);
+    uint32_t cw = west_of(cur.a.x), ce = east_of(cur.a.x);  // of the row about to be processed
+
+    for (int g = g0; g < g1; g++) {
+        const Rows nx3 = load_rows(g + 3);
+        const uint32_t w[9] = {cur.a.x, cur.a.y, cur.a.z, cur.a.w, cur.b.x, cur.b.y, cur.b.z, cur.b.w, nx1.a.x};
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const uint32_t c = w[r], sd = w[r + 1];
+            const uint32_t sw = west_of(sd), se = east_of(sd);
+            const uint32_t above = pc | pw | pe;  // some foreground 8-adjacent in the row above
+            uint32_t outer = c & ~(cw | above) & om;
+            if (dropIsolated) outer &= (ce | sw | sd | se);
+            uint32_t hole = ~c & cw & pc & hm;
+            const int y = 8 * g + r;
+            if (__any(outer != 0)) {
                 // the run that starts here must not touch the row above anywhere
                 outer &= ~fill_down(above, c);
                 // a run that leaves the word through bit 31 is followed into the next words
@@ -201,10 +160,10 @@ __global__ __launch_bounds__(256) void k_contour_starts(const uint32_t* __restri
                     if (outer & top) {
                         bool bad = false;
                         for (int k = bx + 1; k < WS; k++) {
-                            const uint32_t ck = pw(plane, WS, H, k, y);
+                            const uint32_t ck = pw_at(plane, WS, H, k, y);
                             if (!(ck & 1u)) break;
-                            const uint32_t nk = pw(plane, WS, H, k, y - 1);
-                            const uint32_t nkl = pw(plane, WS, H, k - 1, y - 1), nkr = pw(plane, WS, H, k + 1, y - 1);
+                            const uint32_t nk = pw_at(plane, WS, H, k, y - 1);
+                            const uint32_t nkl = pw_at(plane, WS, H, k - 1, y - 1), nkr = pw_at(plane, WS, H, k + 1, y - 1);
                             const uint32_t ab = nk | (nk << 1) | (nkl >> 31) | (nk >> 1) | (nkr << 31);
                             const int tt = __ffs(~ck) - 1;  // run covers bits [0,tt), tt = -1 means all 32
                             const uint32_t rmask = (tt < 0) ? 0xFFFFFFFFu : ((1u << tt) - 1u);
@@ -214,24 +173,18 @@ __global__ __launch_bounds__(256) void k_contour_starts(const uint32_t* __restri
                         if (bad) outer &= ~top;
                     }
                 }
-                if (dropIsolated && outer) {
-                    const uint32_t e = (c >> 1) | (cr << 31);
-                    const uint32_t sw = (sd << 1) | (sl >> 31);
-                    const uint32_t se = (sd >> 1) | (sr << 31);
-                    outer &= (e | sw | sd | se);
-                }
             }
-            if (hole) {
+            if (__any(hole != 0)) {
                 // the zero run that starts here must have foreground directly above all along
-                hole &= ~fill_down(~n, ~c);
+                hole &= ~fill_down(~pc, ~c);
                 if (!(c >> 31) && hole) {
                     const uint32_t top = 1u << (32 - __clz(c));  // lowest bit of the zero run ending at bit 31
                     if (hole & top) {
                         bool bad = false;
                         for (int k = bx + 1; k < WS; k++) {
-                            const uint32_t zk = ~pw(plane, WS, H, k, y);
+                            const uint32_t zk = ~pw_at(plane, WS, H, k, y);
                             if (!(zk & 1u)) break;
-                            const uint32_t nz = ~pw(plane, WS, H, k, y - 1);
+                            const uint32_t nz = ~pw_at(plane, WS, H, k, y - 1);
                             const int tt = __ffs(~zk) - 1;
                             const uint32_t rmask = (tt < 0) ? 0xFFFFFFFFu : ((1u << tt) - 1u);
                             if (nz & rmask) { bad = true; break; }
@@ -241,39 +194,37 @@ __global__ __launch_bounds__(256) void k_contour_starts(const uint32_t* __restri
                     }
                 }
             }
-        }
-        // ---- append this round's starts: one layer of the wave at a time (a word rarely holds more than one) ----
-        {
-            const uint32_t f = fs / (unsigned int)S, sc = fs % (unsigned int)S;
-            const uint32_t rowPos = (uint32_t)y * W + 32u * bx;
-            uint32_t mo = outer, mh = hole;
-            for (;;) {
-                const bool has = (mo | mh) != 0;
-                const unsigned long long bal = __ballot(has);
-                if (!bal) break;
-                const unsigned int layer = (unsigned int)__popcll(bal);
-                if (staged + layer > (unsigned int)kStage) flush();
-                if (has) {
-                    uint64_t v;
-                    if (mo) {
-                        v = pack_cand(f, 0, sc, rowPos + (__ffs(mo) - 1));
-                        mo &= mo - 1;
-                    } else {
-                        // the start pixel of a hole border is the pixel left of the hole's first pixel
-                        v = pack_cand(f, 1, sc, rowPos + (__ffs(mh) - 1) - 1);
-                        mh &= mh - 1;
+            // ---- append this row's starts: one layer of the wave at a time (a word rarely holds more than one) ----
+            if (__any((outer | hole) != 0)) {
+                const uint32_t rowPos = (uint32_t)y * W + 32u * bx;
+                uint32_t mo = outer, mh = hole;
+                for (;;) {
+                    const bool has = (mo | mh) != 0;
+                    const unsigned long long bal = __ballot(has);
+                    if (!bal) break;
+                    const unsigned int layer = (unsigned int)__popcll(bal);
+                    if (staged + layer > (unsigned int)kStage) flush();
+                    if (has) {
+                        uint64_t v;
+                        if (mo) {
+                            v = pack_cand(f, 0, sc, rowPos + (__ffs(mo) - 1));
+                            mo &= mo - 1;
+                        } else {
+                            // the start pixel of a hole border is the pixel left of the hole's first pixel
+                            v = pack_cand(f, 1, sc, rowPos + (__ffs(mh) - 1) - 1);
+                            mh &= mh - 1;
+                        }
+                        stage[staged + (unsigned int)__popcll(bal & ((1ull << lane) - 1ull))] = v;
                     }
-                    stage[staged + (unsigned int)__popcll(bal & ((1ull << lane) - 1ull))] = v;
+                    staged += layer;
                 }
-                staged += layer;
             }
+            pc = c; pw = cw; pe = ce;
+            cw = sw; ce = se;
         }
-        prevO = np != 0 ? curO : kZero;
-        cur = nxt;
-        curO = nxtO;
-        nxt = nxt2;
-        p = np; by = nby; fs = nfs;
-        np = np2; nby = nby2; nfs = nfs2;
+        cur = nx1;
+        nx1 = nx2;
+        nx2 = nx3;
     }
     flush();
 }
@@ -1161,10 +1112,18 @@ __global__ __launch_bounds__(256) void k_trace_copy(const uint32_t* __restrict__
 }  // namespace
 
 void launch_contour_starts(const DetCfg& c, const DetBuffers& b, int B, hipStream_t st) {
-    const unsigned long long units = (unsigned long long)B * c.nScales * plane_hb(c.H) * ((c.WS + 1) / 2);
-    const unsigned long long want = (units + 63) / 64;  // at least ~16 rounds per wave (4 waves per block)
-    const unsigned blocks = (unsigned)(want < 1 ? 1 : (want < (unsigned long long)(256 * 32) ? want : (unsigned long long)(256 * 32)));
-    hipLaunchKernelGGL(k_contour_starts, dim3(blocks), dim3(256), 0, st, b.planes, c, B, b.cand, b.candCap, b.counters);
+    // one wavefront per (plane, group of 62 block columns, band of rows); bands of a plane only when there are too
+    // few planes to fill the chip (each band re-reads one row), in whole groups of eight rows
+    const int colGroups = (c.WS + kStartCols - 1) / kStartCols;
+    const long long waves = (long long)B * c.nScales * colGroups;
+    const int totalGroups = plane_hb(c.H) * 4;
+    int bands = 1;
+    if (waves < 256 * 16) bands = (int)std::min<long long>((256 * 16 + waves - 1) / waves, (totalGroups + 3) / 4);
+    const int bandGroups = (totalGroups + bands - 1) / bands;
+    bands = (totalGroups + bandGroups - 1) / bandGroups;
+    const long long grid = waves * bands;
+    hipLaunchKernelGGL(k_contour_starts, dim3((unsigned)grid), dim3(64), 0, st, b.planes, c, B, bands, bandGroups, b.cand, b.candCap,
+                       b.counters);
 }
 
 void launch_trace(const DetCfg& c, const DetBuffers& b, hipStream_t st) {

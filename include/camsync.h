@@ -129,6 +129,10 @@ int camsync_debug_lists(camsync_ctx* ctx, uint32_t used[8], uint32_t cap[8]);
  * pixel on the device; here one byte per pixel, 0 or 1, [H,W]): cv.adaptiveThreshold(MEAN_C, BINARY_INV) with the
  * image's outermost pixel frame cleared, which is what findContours sees. */
 int camsync_debug_planes(camsync_ctx* ctx, int frame, int scale, uint8_t* out_bits);
+/* The first two stages alone (gray + thresholds, contour-start candidates) on B host frames (B <= max_batch): the
+ * candidate list, unordered, each entry frame << 40 | hole << 39 | scale << 36 | (y * W + x) of the start pixel.
+ * Returns the number of candidates found (may exceed max_starts), or < 0. */
+int camsync_debug_starts(camsync_ctx* ctx, const uint8_t* frames, int B, int H, int W, int C, int max_starts, uint64_t* out);
 int camsync_debug_quads(camsync_ctx* ctx, int frame, int max_quads, float* corners,
                         int32_t* scale, int32_t* scan_key, int32_t* contour_len,
                         int32_t* id, int32_t* rot);

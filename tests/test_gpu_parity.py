@@ -289,3 +289,84 @@ def test_pipeline_threshold_planes_bit_exact(size, channels):
             want[:, 0] = want[:, -1] = 0
             got = c.debug_planes(b, s, H, W)
             assert np.array_equal(got, want), (b, win, int((got != want).sum()))
+
+
+def _start_rule(binimg):
+    """Contour-start candidates of one threshold image by the rule k_contour_starts implements, restated pixel by
+    pixel: an outer candidate is a foreground pixel with background to its west whose horizontal run has no
+    foreground 8-adjacent in the row above anywhere along it, and that is not an isolated pixel; a hole candidate is
+    a background pixel with foreground to its west and directly above all along its zero run (the start pixel is the
+    pixel to its west).  Returns sorted (hole << 39 | y * W + x)."""
+    b = (binimg > 0).astype(np.uint8)
+    H, W = b.shape
+    b[0, :] = b[-1, :] = 0
+    b[:, 0] = b[:, -1] = 0
+    p = np.pad(b, 1)
+    up = p[:-2]                                   # rows y-1, padded columns
+    above = up[:, :-2] | up[:, 1:-1] | up[:, 2:]  # NW | N | NE
+    n_ = up[:, 1:-1]
+    west = p[1:-1, :-2]
+    east = p[1:-1, 2:]
+    dn = p[2:]
+    below = dn[:, :-2] | dn[:, 1:-1] | dn[:, 2:]
+    out = []
+    for y in range(H - 1):
+        row = b[y]
+        # runs of foreground
+        d = np.diff(np.concatenate([[0], row, [0]]).astype(np.int8))
+        s_, e_ = np.flatnonzero(d == 1), np.flatnonzero(d == -1)
+        if len(s_):
+            ca = np.concatenate([[0], np.cumsum(above[y])])
+            ok = (ca[e_] - ca[s_]) == 0
+            iso = (e_ - s_ == 1) & (below[y][s_] == 0)
+            for x in s_[ok & ~iso]:
+                out.append(y * W + int(x))
+        # zero runs that begin right of a foreground pixel
+        z = 1 - row
+        d = np.diff(np.concatenate([[0], z, [0]]).astype(np.int8))
+        s_, e_ = np.flatnonzero(d == 1), np.flatnonzero(d == -1)
+        keep = s_ > 0
+        s_, e_ = s_[keep], e_[keep]
+        if len(s_):
+            cz = np.concatenate([[0], np.cumsum(1 - n_[y])])
+            ok = ((cz[e_] - cz[s_]) == 0)
+            for x in s_[ok]:
+                out.append((1 << 39) | (y * W + int(x) - 1))
+    return np.sort(np.array(out, np.uint64))
+
+
+@pytest.mark.parametrize("case", ["pic_2", "noise", "blocks_136", "synthetic_1080p", "grid_4k", "wide_4088"])
+def test_contour_start_candidates_match_the_rule(case):
+    """The candidate list of the start stage (before any border is followed) equals the pixel-by-pixel rule on every
+    threshold scale: nothing missing (a lost contour) and nothing extra (wasted border following)."""
+    from cameracalibration_amd import _hip, synth
+    rng = np.random.default_rng(17)
+    if case == "pic_2":
+        frames = _data.load_bgr("pic_2.png")[None]
+    elif case == "noise":
+        frames = rng.integers(0, 256, (2, 96, 128, 3), dtype=np.uint8)
+    elif case == "blocks_136":
+        small = rng.integers(0, 2, (13, 17), dtype=np.uint8) * 200 + 20
+        img = np.kron(small, np.ones((8, 8), np.uint8))[:100, :136]
+        frames = np.clip(img.astype(np.int32) + rng.integers(-6, 7, img.shape), 0, 255).astype(np.uint8)[None, :, :, None]
+    elif case == "synthetic_1080p":
+        K, _ = _data.calibration("Logitec_robot_1920-1080_10.npz")
+        frames = np.stack([synth.v1_frame(80 + i, K, ss=2, device="cuda")[0].cpu().numpy() for i in range(3)])
+    elif case == "grid_4k":
+        K4 = np.array([[2800.0, 0, 1920.0], [0, 2800.0, 1080.0], [0, 0, 1.0]])
+        frames = synth.grid_frame(30, K4, ss=2, device="cuda")[0].cpu().numpy()[None]
+    else:  # widest supported frame: 128 words per row, three column groups, a partly used last word
+        small = rng.integers(0, 2, (8, 511), dtype=np.uint8) * 200 + 20
+        img = np.kron(small, np.ones((8, 8), np.uint8))[:64, :4088]
+        frames = np.clip(img.astype(np.int32) + rng.integers(-6, 7, img.shape), 0, 255).astype(np.uint8)[None, :, :, None]
+    B, H, W, C = frames.shape
+    c = _hip.Context(H, W, B)
+    got = c.debug_starts(frames)
+    want = []
+    for b in range(B):
+        gray = frames[b, :, :, 0] if C == 1 else orc.bgr2gray(frames[b])
+        for s, win in enumerate((3, 13, 23)):
+            r = _start_rule(orc.adaptive_threshold(gray, win))
+            want.append(r | np.uint64((b << 40) | (s << 36)))
+    want = np.sort(np.concatenate(want))
+    assert len(got) == len(want) and np.array_equal(got, want), (len(got), len(want))
