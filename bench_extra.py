@@ -135,10 +135,26 @@ def main():
             lat = np.array(lat)
             out["config5_8cams_%dx%d" % (w, h)] = {
                 "sets": args.sets, "p50_ms": float(np.percentile(lat, 50)), "p99_ms": float(np.percentile(lat, 99)),
-                "note": "8 host frames per set, per-camera loop of the mirror API (detect + PnP + locate), "
+                "note": "8 host frames (pageable memory) per set through the mirror API: one detection + anchor-PnP "
+                        "launch sequence for all cameras, one IPPE call for all moving markers, fusion on the host; "
                         "includes the host-to-device copies"}
         except Exception as e:
             out["config5_8cams_%dx%d" % (w, h)] = {"error": "%s: %s" % (type(e).__name__, e)}
+
+    # ---- single frame: detectAruco on one host frame ----
+    try:
+        one = synth.v1_frame(100, K, H=1080, W=1920, device=dev, ss=2)[0].cpu().numpy()
+        A.detectAruco(one)
+        lat = []
+        for _ in range(args.sets):
+            t0 = time.perf_counter()
+            A.detectAruco(one)
+            lat.append((time.perf_counter() - t0) * 1e3)
+        out["single_frame_1920x1080_detectAruco"] = {"sets": args.sets, "p50_ms": float(np.percentile(lat, 50)),
+                                                     "p99_ms": float(np.percentile(lat, 99)),
+                                                     "note": "one pageable host frame in, dict of corners out"}
+    except Exception as e:
+        out["single_frame_1920x1080_detectAruco"] = {"error": "%s: %s" % (type(e).__name__, e)}
 
     # ---- one launch sequence for the same 8 frames (detectArucoBatch + processArucoBatch) ----
     try:

@@ -106,6 +106,7 @@ def load_library() -> C.CDLL:
         lib.camsync_ippe_square_batch.argtypes = [vp, vp, vp, i32, vp, vp, i32, i32, vp, vp, vp]
         lib.camsync_detect_pnp_batch.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp, i32, i32,
                                                  i32, vp, vp, vp, vp, vp, vp, vp, vp]
+        lib.camsync_detect_pnp_frames.argtypes = lib.camsync_detect_pnp_batch.argtypes
         lib.camsync_detect_pnp_resident.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, i32, vp, vp, i32,
                                                     i32, vp, vp, vp, vp, vp, vp]
         lib.camsync_calibrate.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp]
@@ -334,6 +335,30 @@ class Context:
         mae = np.zeros(B); rmse = np.zeros(B)
         self._check(self._lib.camsync_detect_pnp_batch(
             self._h, _ptr(f), 0, B, H, W, Cn, _ptr(anchor_ids), _ptr(anchor_obj), len(anchor_ids), _ptr(K), _ptr(d),
+            d.shape[1], per_frame, max_markers, _ptr(ids), _ptr(corners), _ptr(counts), _ptr(rvec), _ptr(tvec),
+            _ptr(ok), _ptr(mae), _ptr(rmse)))
+        return ids, corners, counts, rvec, tvec, ok, mae, rmse
+
+    def detect_pnp_frames(self, frames, anchor_ids, anchor_obj, K, dist, max_markers: int = 64):
+        """camsync_detect_pnp_frames: `frames` is a sequence of B separate [H,W,C] uint8 host arrays of one shape
+        (one per camera); K [B,3,3] / dist [B,n] per frame, or one camera for all.  Results as detect_pnp."""
+        fs = [np.ascontiguousarray(f, dtype=np.uint8) for f in frames]
+        fs = [f[..., None] if f.ndim == 2 else f for f in fs]
+        B = len(fs)
+        H, W, Cn = fs[0].shape
+        if any(f.shape != (H, W, Cn) for f in fs):
+            raise ValueError("all frames of one call must have the same shape")
+        ptrs = (C.c_void_p * B)(*[f.ctypes.data for f in fs])
+        anchor_ids = np.ascontiguousarray(anchor_ids, dtype=np.int32)
+        anchor_obj = np.ascontiguousarray(anchor_obj, dtype=np.float32).reshape(len(anchor_ids), 4, 3)
+        K, d, per_frame = _cam(K, dist, B)
+        ids = np.full((B, max_markers), -1, np.int32)
+        corners = np.zeros((B, max_markers, 4, 2), np.float32)
+        counts = np.zeros(B, np.int32)
+        rvec = np.zeros((B, 3)); tvec = np.zeros((B, 3)); ok = np.zeros(B, np.uint8)
+        mae = np.zeros(B); rmse = np.zeros(B)
+        self._check(self._lib.camsync_detect_pnp_frames(
+            self._h, ptrs, 0, B, H, W, Cn, _ptr(anchor_ids), _ptr(anchor_obj), len(anchor_ids), _ptr(K), _ptr(d),
             d.shape[1], per_frame, max_markers, _ptr(ids), _ptr(corners), _ptr(counts), _ptr(rvec), _ptr(tvec),
             _ptr(ok), _ptr(mae), _ptr(rmse)))
         return ids, corners, counts, rvec, tvec, ok, mae, rmse

@@ -226,15 +226,94 @@ def PnP(image_points, object_points, mtx, dist, getMetrics=False):
     return rvec.reshape(3, 1), tvec.reshape(3, 1), metrics
 
 
+def _process_cameras_batched(fixedArucos, movingArucos, cameras, frames, metrics):
+    """processAruco(..., accept_none=True, directUpdate=False) for every (camera, frame) pair, with the GPU work of
+    all cameras in two launch sequences instead of two per camera: one detection + anchor PnP over all frames
+    (camsync_detect_pnp_frames, a camera matrix per frame) and one IPPE solve over all moving markers seen.
+    Same kernels and same inputs as the per-camera calls, so the results are identical; the cameras are updated in
+    order, and an error is raised where the per-camera loop would have raised it.
+    Returns one entry per camera: False, or (rvec, tvec, {id: aruco2world}, metrics_collected)."""
+    n = len(cameras)
+    fixedArucos = list(fixedArucos)
+    movingArucos = list(movingArucos)
+    fs = [_as_frame(f) for f in frames]
+    anchor_ids = np.array([a.id for a in fixedArucos], dtype=np.int32)
+    anchor_obj = (np.stack([a.getCornersAsList() for a in fixedArucos]).astype(np.float32)
+                  if fixedArucos else np.zeros((0, 4, 3), np.float32))
+    det = [None] * n  # per camera: (detected dict, rvec, tvec, ok, mae, rmse)
+    groups = {}
+    for i, f in enumerate(fs):
+        groups.setdefault(f.shape, []).append(i)
+    for shape, idx in groups.items():
+        ks = np.stack([np.asarray(cameras[i].mtx, np.float64).reshape(3, 3) for i in idx])
+        nd = max(np.asarray(cameras[i].dist).size for i in idx)
+        ds = np.zeros((len(idx), nd))
+        for k, i in enumerate(idx):
+            d = np.asarray(cameras[i].dist, np.float64).ravel()
+            ds[k, :d.size] = d
+        ctx = _hip.get_context(shape[0], shape[1], len(idx))
+        ids, corners, counts, rvec, tvec, ok, mae, rmse = ctx.detect_pnp_frames([fs[i] for i in idx], anchor_ids, anchor_obj, ks, ds)
+        for k, i in enumerate(idx):
+            found = {np.int32(ids[k, m]): corners[k, m].reshape(1, 4, 2).copy() for m in range(int(counts[k]))}
+            det[i] = (found, rvec[k], tvec[k], int(ok[k]), float(mae[k]), float(rmse[k]))
+    # the moving markers every located camera sees, in the order processAruco visits them
+    pairs = []
+    for i in range(n):
+        found, _, _, ok, _, _ = det[i]
+        if sum(1 for a in fixedArucos if found.get(a.id) is not None) >= 1 and ok == 1:
+            pairs.extend((i, a) for a in movingArucos if found.get(a.id) is not None)
+    poses = {}
+    if pairs:
+        ctx = _hip.get_context(8, 8, 1)
+        pc = np.stack([det[i][0][a.id].reshape(4, 2) for i, a in pairs]).astype(np.float32)
+        pk = np.stack([np.asarray(cameras[i].mtx, np.float64).reshape(3, 3) for i, _ in pairs])
+        nd = max(np.asarray(cameras[i].dist).size for i, _ in pairs)
+        pd = np.zeros((len(pairs), nd))
+        for k, (i, _) in enumerate(pairs):
+            d = np.asarray(cameras[i].dist, np.float64).ravel()
+            pd[k, :d.size] = d
+        rv, tv, _ = ctx.ippe_square(pc, np.array([float(a.size) for _, a in pairs]), pk, pd)
+        for k, (i, a) in enumerate(pairs):
+            poses[(i, a.id)] = (rv[k].reshape(3, 1), tv[k].reshape(3, 1))
+    out = []
+    for i, cam in enumerate(cameras):
+        found, rvec, tvec, ok, mae, rmse = det[i]
+        if 4 * sum(1 for a in fixedArucos if found.get(a.id) is not None) < 4:
+            out.append(False)
+            continue
+        if ok == 2:
+            raise _hip.CamsyncError(-1, "solvePnP on non-coplanar object points is not supported by the HIP path")
+        if ok != 1:
+            raise Exception("Could not solve PnP")
+        rvec, tvec = rvec.reshape(3, 1), tvec.reshape(3, 1)
+        collected = {"PnP": {"MAE": mae, "RMSE": rmse}} if metrics else {}
+        cam.updateWorldPosition(rvec, tvec, noLowPassFilter=False)
+        located = {}
+        for a in movingArucos:
+            if (i, a.id) not in poses:
+                continue
+            r, t = poses[(i, a.id)]
+            located[a.id] = Transform.fromRodrigues(rvec=r, tvec=t).combine(cam.world2cam.invert)
+        out.append((rvec, tvec, located, collected))
+    return out
+
+
 def processArucoFromMultipleCameras(fixedArucos, movingArucos: dict, cameras, frame, getMetrics=False):
     """All cameras look at the same scene (aruco.py:407-470): every camera that sees enough anchors locates
     itself and the moving markers it sees; each moving marker's world corners are averaged over the cameras
-    and low-passed into Aruco.corners."""
+    and low-passed into Aruco.corners.  The per-camera loop of the reference (aruco.py:417) is one batch here
+    (_process_cameras_batched); the results are those of the loop."""
     assert len(cameras) == len(frame)
+    fixedArucos = list(fixedArucos)
+    batchable = (0 < len(fixedArucos) <= 16 and len(cameras) > 0
+                 and all(getattr(c, "mtx", None) is not None and getattr(c, "dist", None) is not None for c in cameras))
+    if batchable:
+        results = _process_cameras_batched(fixedArucos, movingArucos.values(), cameras, frame, getMetrics)
+    else:  # nothing to batch over, or more anchors than the fused kernel gathers: the reference's own loop
+        results = [processAruco(fixedArucos, movingArucos.values(), cam, f, accept_none=True, directUpdate=False,
+                                metrics=getMetrics) for cam, f in zip(cameras, frame)]
     seen_corners = {}  # id -> one [4][3] list per camera that saw the marker
-    for cam, f in zip(cameras, frame):
-        res = processAruco(fixedArucos, movingArucos.values(), cam, f, accept_none=True, directUpdate=False,
-                           metrics=getMetrics)
+    for res in results:
         if not res:
             continue
         _, _, located, _ = res

@@ -79,8 +79,10 @@ class Transform:
         return Transform.fromRotationMatrix(rot_mat=rodrigues_to_matrix(np.array(rvec).flatten()), tvec=tvec)
 
     def __init__(self, transf_mat=None):
+        # The reference derives rvec and the quaternion on every construction (referential.py:82-84, an SVD and a
+        # scipy call).  They are derived on first use here: the per-frame path builds several transforms per camera
+        # and marker and reads neither, and the values are the same either way.
         self._transf_mat = transf_mat
-        self._preCompute()
 
     def _preCompute(self):
         # referential.py:82-84
@@ -103,6 +105,8 @@ class Transform:
 
     @property
     def rvec(self):
+        if self._rvec is None:
+            self._rvec = matrix_to_rodrigues(self.rot_mat)
         return self._rvec
 
     @property

@@ -55,6 +55,9 @@ struct camsync_ctx {
     double* d_focalRows = nullptr;
     double* d_focalAcc = nullptr;  // = d_calWork + kWFocal
     double* h_pin = nullptr;       // pinned host doubles for the small read-backs of the LM loop
+    // pinned host copies of a chunk's detection results (allocated on first use, kept for the context's life)
+    int32_t *h_ids = nullptr, *h_counts = nullptr, *h_rejCounts = nullptr;
+    float *h_corners = nullptr, *h_rej = nullptr;
     uint8_t* d_calOk = nullptr;
     double* d_calK = nullptr;
     int32_t* d_calNpts = nullptr;
@@ -223,6 +226,19 @@ int ensure_staging(camsync_ctx* c) {
 int ensure_gray(camsync_ctx* c) {
     if (c->buf.gray) return CAMSYNC_OK;
     HIPCHK(c, dalloc(&c->buf.gray, (size_t)c->maxB * c->maxH * c->maxW));
+    return CAMSYNC_OK;
+}
+
+int ensure_host_out(camsync_ctx* c, bool wantRejected) {
+    const size_t B = (size_t)c->maxB;
+    if (!c->h_ids) {
+        HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_ids), sizeof(int32_t) * B * kMaxMarkerOut, hipHostMallocDefault));
+        HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_corners), sizeof(float) * B * kMaxMarkerOut * 8, hipHostMallocDefault));
+        HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_counts), sizeof(int32_t) * B, hipHostMallocDefault));
+        HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_rejCounts), sizeof(int32_t) * B, hipHostMallocDefault));
+    }
+    if (wantRejected && !c->h_rej)
+        HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_rej), sizeof(float) * B * kMaxRejectedOut * 8, hipHostMallocDefault));
     return CAMSYNC_OK;
 }
 
@@ -486,6 +502,9 @@ void camsync_destroy(camsync_ctx* c) {
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
+    void* hostPtrs[] = {c->h_ids, c->h_corners, c->h_counts, c->h_rejCounts, c->h_rej};
+    for (void* p : hostPtrs)
+        if (p) (void)hipHostFree(p);
     for (int i = 0; i <= CAMSYNC_N_STAGES; i++)
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -567,13 +586,17 @@ int camsync_gray_threshold(camsync_ctx* c, const uint8_t* frames, int on_device,
     return CAMSYNC_OK;
 }
 
-static int detect_impl(camsync_ctx* c, const uint8_t* frames, int on_device, int B, int H, int W, int C,
+// `frames` is one contiguous batch, or (frame_ptrs != null) B separate frames, e.g. one per camera
+static int detect_impl(camsync_ctx* c, const uint8_t* frames, const uint8_t* const* frame_ptrs, int on_device, int B, int H, int W, int C,
                        int max_markers, int32_t* ids, float* corners, int32_t* counts, int max_rejected, float* rejected,
                        int32_t* rej_counts, const int32_t* anchor_ids, const float* anchor_obj, int n_anchor,
                        const double* K, const double* dist, int ndist, int per_frame_cam, double* rvec, double* tvec,
                        uint8_t* pose_ok, double* mae, double* rmse, bool withPose) {
-    int rc = check_frame_args(c, frames, B, H, W, C);
+    int rc = check_frame_args(c, frame_ptrs ? (const void*)frame_ptrs : (const void*)frames, B, H, W, C);
     if (rc) return rc;
+    if (frame_ptrs)
+        for (int i = 0; i < B; i++)
+            if (!frame_ptrs[i]) return fail(c, CAMSYNC_E_ARG, "frame %d is NULL", i);
     if (c->dictN <= 0) return fail(c, CAMSYNC_E_ARG, "no dictionary set (camsync_set_dictionary)");
     if (max_markers < 1 || !ids || !corners || !counts) return fail(c, CAMSYNC_E_ARG, "detection outputs missing");
     if (withPose) {
@@ -584,9 +607,10 @@ static int detect_impl(camsync_ctx* c, const uint8_t* frames, int on_device, int
     }
     HIPCHK(c, hipSetDevice(c->device));
     const size_t px = (size_t)H * W;
-    std::vector<int32_t> hIds((size_t)c->maxB * kMaxMarkerOut), hCounts(c->maxB), hRejCounts(c->maxB);
-    std::vector<float> hCorners((size_t)c->maxB * kMaxMarkerOut * 8), hRej;
-    if (rejected) hRej.resize((size_t)c->maxB * kMaxRejectedOut * 8);
+    rc = ensure_host_out(c, rejected != nullptr);
+    if (rc) return rc;
+    int32_t *const hIds = c->h_ids, *const hCounts = c->h_counts, *const hRejCounts = c->h_rejCounts;
+    float *const hCorners = c->h_corners, *const hRej = c->h_rej;
     if (withPose) {
         rc = ensure_pose_scratch(c, (size_t)c->maxB, 64);
         if (rc) return rc;
@@ -595,9 +619,16 @@ static int detect_impl(camsync_ctx* c, const uint8_t* frames, int on_device, int
     }
     for (int b0 = 0; b0 < B; b0 += c->maxB) {
         const int nb = std::min(c->maxB, B - b0);
-        const uint8_t* src = frames + (size_t)b0 * px * C;
+        const uint8_t* src = frame_ptrs ? nullptr : frames + (size_t)b0 * px * C;
         const uint8_t* d_in = src;
-        if (!on_device) {
+        if (frame_ptrs) {  // separate frames (host or device) are gathered into the staging buffer
+            int rcs = ensure_staging(c);
+            if (rcs) return rcs;
+            for (int i = 0; i < nb; i++)
+                HIPCHK(c, hipMemcpyAsync(c->d_in + (size_t)i * px * C, frame_ptrs[b0 + i], px * C,
+                                         on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+            d_in = c->d_in;
+        } else if (!on_device) {
             int rcs = ensure_staging(c);
             if (rcs) return rcs;
             HIPCHK(c, hipMemcpyAsync(c->d_in, src, (size_t)nb * px * C, hipMemcpyHostToDevice, c->stream));
@@ -627,12 +658,12 @@ static int detect_impl(camsync_ctx* c, const uint8_t* frames, int on_device, int
             if (mae) HIPCHK(c, hipMemcpyAsync(mae + b0, c->d_mae, sizeof(double) * nb, hipMemcpyDeviceToHost, c->stream));
             if (rmse) HIPCHK(c, hipMemcpyAsync(rmse + b0, c->d_rmse, sizeof(double) * nb, hipMemcpyDeviceToHost, c->stream));
         }
-        HIPCHK(c, hipMemcpyAsync(hIds.data(), c->buf.outIds, sizeof(int32_t) * nb * kMaxMarkerOut, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(hCorners.data(), c->buf.outCorners, sizeof(float) * nb * kMaxMarkerOut * 8, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(hCounts.data(), c->buf.outCounts, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(hIds, c->buf.outIds, sizeof(int32_t) * nb * kMaxMarkerOut, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(hCorners, c->buf.outCorners, sizeof(float) * nb * kMaxMarkerOut * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(hCounts, c->buf.outCounts, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, c->stream));
         if (rejected) {
-            HIPCHK(c, hipMemcpyAsync(hRej.data(), c->buf.outRejected, sizeof(float) * nb * kMaxRejectedOut * 8, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipMemcpyAsync(hRejCounts.data(), c->buf.outRejCounts, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(hRej, c->buf.outRejected, sizeof(float) * nb * kMaxRejectedOut * 8, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(hRejCounts, c->buf.outRejCounts, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, c->stream));
         }
         rc = check_overflow(c);  // synchronises the stream
         if (rc) return rc;
@@ -659,7 +690,7 @@ static int detect_impl(camsync_ctx* c, const uint8_t* frames, int on_device, int
 int camsync_detect_batch(camsync_ctx* c, const uint8_t* frames, int on_device, int B, int H, int W, int C,
                          int max_markers, int32_t* ids, float* corners, int32_t* counts, int max_rejected,
                          float* rejected, int32_t* rej_counts) {
-    return detect_impl(c, frames, on_device, B, H, W, C, max_markers, ids, corners, counts, max_rejected, rejected,
+    return detect_impl(c, frames, nullptr, on_device, B, H, W, C, max_markers, ids, corners, counts, max_rejected, rejected,
                        rej_counts, nullptr, nullptr, 0, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, false);
 }
 
@@ -668,7 +699,18 @@ int camsync_detect_pnp_batch(camsync_ctx* c, const uint8_t* frames, int on_devic
                              const double* dist, int ndist, int per_frame_cam, int max_markers, int32_t* ids,
                              float* corners, int32_t* counts, double* rvec, double* tvec, uint8_t* pose_ok, double* mae,
                              double* rmse) {
-    return detect_impl(c, frames, on_device, B, H, W, C, max_markers, ids, corners, counts, 0, nullptr, nullptr,
+    return detect_impl(c, frames, nullptr, on_device, B, H, W, C, max_markers, ids, corners, counts, 0, nullptr, nullptr,
+                       anchor_ids, anchor_obj, n_anchor, K, dist, ndist, per_frame_cam, rvec, tvec, pose_ok, mae, rmse, true);
+}
+
+int camsync_detect_pnp_frames(camsync_ctx* c, const uint8_t* const* frame_ptrs, int on_device, int B, int H, int W, int C,
+                              const int32_t* anchor_ids, const float* anchor_obj, int n_anchor, const double* K,
+                              const double* dist, int ndist, int per_frame_cam, int max_markers, int32_t* ids,
+                              float* corners, int32_t* counts, double* rvec, double* tvec, uint8_t* pose_ok, double* mae,
+                              double* rmse) {
+    if (!c) return CAMSYNC_E_ARG;
+    if (!frame_ptrs) return fail(c, CAMSYNC_E_ARG, "frame_ptrs is NULL");
+    return detect_impl(c, nullptr, frame_ptrs, on_device, B, H, W, C, max_markers, ids, corners, counts, 0, nullptr, nullptr,
                        anchor_ids, anchor_obj, n_anchor, K, dist, ndist, per_frame_cam, rvec, tvec, pose_ok, mae, rmse, true);
 }
 

@@ -194,6 +194,18 @@ int camsync_detect_pnp_batch(camsync_ctx* ctx, const uint8_t* frames, int on_dev
                              int max_markers, int32_t* ids, float* corners, int32_t* counts,
                              double* rvec, double* tvec, uint8_t* pose_ok, double* mae, double* rmse);
 
+/* camsync_detect_pnp_batch for B frames that do not lie in one buffer -- one frame per camera, as
+ * processArucoFromMultipleCameras receives them (aruco.py:407-417: `for c, f in zip(cameras, frame)`): frame_ptrs[i]
+ * is frame i, [H,W,C] u8, host or device memory (pinned host memory copies fastest).  The frames are gathered on the
+ * GPU and go through one launch sequence; with per_frame_cam = 1 every frame has its own camera matrix and distortion.
+ * Results as camsync_detect_pnp_batch. */
+int camsync_detect_pnp_frames(camsync_ctx* ctx, const uint8_t* const* frame_ptrs, int on_device,
+                              int B, int H, int W, int C,
+                              const int32_t* anchor_ids, const float* anchor_obj, int n_anchor,
+                              const double* K, const double* dist, int ndist, int per_frame_cam,
+                              int max_markers, int32_t* ids, float* corners, int32_t* counts,
+                              double* rvec, double* tvec, uint8_t* pose_ok, double* mae, double* rmse);
+
 /* Same pipeline, inputs already resident on the GPU and results left on the
  * GPU (no host copies, returns after the stream drained): the benchmark /
  * serving entry point.  d_* are device pointers laid out as above. */

@@ -105,6 +105,72 @@ def test_multiple_cameras_average():
         processArucoFromMultipleCameras([], moving, cams, [frame])
 
 
+def test_multiple_cameras_batched_equals_the_per_camera_loop():
+    """processArucoFromMultipleCameras runs all cameras as one batch; the reference loops over the
+    cameras (aruco.py:417).  Eight 1080p cameras with distinct intrinsics, one camera that sees nothing and one
+    720p camera: camera poses, filtered positions and the fused marker corners must equal the loop's exactly."""
+    import copy
+    from cameracalibration_amd import synth
+    from cameracalibration_amd.camera_sync.aruco import (Aruco, getArucosFromPaper, processAruco,
+                                                         processArucoFromMultipleCameras)
+    from cameracalibration_amd.camera_sync.camera import Camera
+
+    K, _ = _data.calibration("Logitec_robot_1920-1080_10.npz")
+    frames, cams = [], []
+    for i in range(8):
+        cam = Camera("Logitec_robot", -1, focus=10, resolution=(1920, 1080))
+        cam.mtx = cam.mtx.copy()
+        cam.mtx[0, 0] *= 1.0 + 0.01 * i
+        cam.mtx[1, 1] *= 1.0 - 0.005 * i
+        cam.dist = cam.dist * (1.0 + 0.1 * i)
+        frames.append(synth.v1_frame(200 + i, cam.mtx, ss=2, device="cuda")[0].cpu().numpy())
+        cams.append(cam)
+    cams.append(Camera("Logitec_robot", -1, focus=10, resolution=(1920, 1080)))
+    frames.append(np.full((1080, 1920, 3), 90, np.uint8))            # sees nothing: skipped
+    cams.append(Camera("Logitec_A", -1, focus=0, resolution=(1280, 720)))
+    frames.append(_data.load_bgr("pic_2.png"))                        # another resolution: its own batch
+    sheet = getArucosFromPaper(1)
+    fixed = [sheet[i] for i in (10, 11, 14, 15)]
+
+    def run(batched):
+        cs = copy.deepcopy(cams)
+        moving = {k: copy.deepcopy(sheet[k]) for k in (12, 13)}
+        for _ in range(2):  # twice: the low-pass filters carry state from the first set to the second
+            if batched:
+                processArucoFromMultipleCameras(fixed, moving, cs, frames, getMetrics=True)
+            else:
+                seen = {}
+                for cam, f in zip(cs, frames):
+                    res = processAruco(fixed, moving.values(), cam, f, accept_none=True, directUpdate=False, metrics=True)
+                    if not res:
+                        continue
+                    for key, a2w in res[2].items():
+                        size = moving[key].size
+                        local = Aruco.getCornersFromTopLeft(np.array([-size / 2, size / 2, 0]), size)
+                        seen.setdefault(key, []).append([a2w.apply(c) for c in local])
+                for a in moving.values():
+                    if a.id in seen:
+                        for i, p in enumerate(np.mean(seen[a.id], axis=0)):
+                            a.corners[i].updatePos(p)
+        return cs, moving
+
+    cb, mb = run(True)
+    cl, ml = run(False)
+    located = 0
+    for a, b in zip(cb, cl):
+        assert np.array_equal(a.world_position.coords, b.world_position.coords)
+        assert hasattr(a, "world2cam") == hasattr(b, "world2cam")
+        if hasattr(a, "world2cam"):
+            located += 1
+            assert np.array_equal(a.world2cam.transf_mat, b.world2cam.transf_mat)
+    assert located == 9
+    for k in mb:
+        got = np.array([c.coords for c in mb[k].corners], float)
+        want = np.array([c.coords for c in ml[k].corners], float)
+        assert np.array_equal(got, want)
+        assert not np.array_equal(got, np.array([c.coords for c in sheet[k].corners], float))
+
+
 def test_batched_additions_equal_per_frame_calls():
     from cameracalibration_amd import synth
     from cameracalibration_amd.camera_sync.aruco import PnP, detectAruco, detectArucoBatch, processArucoBatch
