@@ -109,6 +109,8 @@ def load_library() -> C.CDLL:
         lib.camsync_detect_pnp_frames.argtypes = lib.camsync_detect_pnp_batch.argtypes
         lib.camsync_detect_pnp_resident.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, i32, vp, vp, i32,
                                                     i32, vp, vp, vp, vp, vp, vp]
+        lib.camsync_optimal_new_camera_matrix.argtypes = [vp, vp, i32, i32, i32, dbl, i32, i32, vp, vp]
+        lib.camsync_undistort_batch.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp]
         lib.camsync_calibrate.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp]
         lib.camsync_calibrate_dist.argtypes = [vp, vp, vp, i32, i32, C.c_int64, i32, i32, i32, i32, ALLREDUCE_FN, vp, vp,
                                                vp, vp, vp, vp, vp, vp]
@@ -374,6 +376,24 @@ class Context:
             _ptr(K), _ptr(d), d.shape[1], max_markers, C.c_void_p(d_ids), C.c_void_p(d_corners), C.c_void_p(d_counts),
             C.c_void_p(d_rvec), C.c_void_p(d_tvec), C.c_void_p(d_ok)))
 
+    # -- undistortion --------------------------------------------------
+    def undistort(self, frames, K, dist, new_K=None):
+        """cv.undistort for a batch [B,H,W,C] (or one frame) of one camera; returns the same shape."""
+        src = np.asarray(frames)
+        f = self._frames(src)
+        B, H, W, Cn = f.shape
+        K = np.ascontiguousarray(K, dtype=np.float64).reshape(3, 3)
+        d = np.zeros(0) if dist is None else np.ascontiguousarray(dist, dtype=np.float64).ravel()
+        if d.size > 8:
+            if np.any(d[8:] != 0):
+                raise ValueError("thin-prism / tilt distortion terms are not supported")
+            d = np.ascontiguousarray(d[:8])
+        nk = None if new_K is None else np.ascontiguousarray(new_K, dtype=np.float64).reshape(3, 3)
+        out = np.empty_like(f)
+        self._check(self._lib.camsync_undistort_batch(self._h, _ptr(f), 0, B, H, W, Cn, _ptr(K), _ptr(d), d.size,
+                                                      _ptr(nk), _ptr(out)))
+        return out.reshape(src.shape)
+
     # -- calibration ---------------------------------------------------
     def calibrate(self, obj, img, image_size, rational=False, max_iter=30):
         obj = np.ascontiguousarray(obj, dtype=np.float32)
@@ -479,6 +499,24 @@ class Context:
         ms = np.zeros(N_STAGES); n = np.zeros(N_STAGES, np.int64)
         self._check(self._lib.camsync_get_timers(self._h, _ptr(ms), _ptr(n)))
         return {STAGE_NAMES[i]: (float(ms[i]), int(n[i])) for i in range(N_STAGES)}
+
+
+def optimal_new_camera_matrix(K, dist, image_size, alpha, new_size=None):
+    """cv.getOptimalNewCameraMatrix(K, dist, (w,h), alpha, new_size) -> (new_K (3,3), roi (x, y, w, h)).  Host only."""
+    lib = load_library()
+    K = np.ascontiguousarray(K, dtype=np.float64).reshape(3, 3)
+    d = np.zeros(0) if dist is None else np.ascontiguousarray(dist, dtype=np.float64).ravel()
+    if d.size > 8:
+        if np.any(d[8:] != 0):
+            raise ValueError("thin-prism / tilt distortion terms are not supported")
+        d = np.ascontiguousarray(d[:8])
+    w, h = int(image_size[0]), int(image_size[1])
+    nw, nh = (int(new_size[0]), int(new_size[1])) if new_size is not None else (w, h)
+    new_K = np.zeros((3, 3)); roi = np.zeros(4, np.int32)
+    rc = lib.camsync_optimal_new_camera_matrix(_ptr(K), _ptr(d), d.size, w, h, float(alpha), nw, nh, _ptr(new_K), _ptr(roi))
+    if rc != 0:
+        raise CamsyncError(rc, "bad arguments to camsync_optimal_new_camera_matrix")
+    return new_K, tuple(int(v) for v in roi)
 
 
 _default_ctx = {}

@@ -2,9 +2,8 @@
 
 On the hot path a Camera is the holder of the intrinsics (`mtx`, `dist`, loaded from
 calibration/<name>_<w>-<h>_<focus>.npz) and of the stateful world pose
-(`world2cam`, low-passed `world_position`).  Frame capture (cv.VideoCapture), the
-chessboard corner finder and image undistortion are outside the scope of this package
-(SURVEY.md section 8(f)); the LM solve behind cv.calibrateCamera is here and runs on the GPU.
+(`world2cam`, low-passed `world_position`).  Frame capture (cv.VideoCapture) is outside the scope of
+this package; image undistortion and the LM solve behind cv.calibrateCamera run on the GPU.
 """
 import os
 
@@ -127,4 +126,12 @@ class Camera:
         return self.world_position, self.world2cam.rot_mat
 
     def undistort(self, img):
-        raise NotImplementedError("image undistortion (camera.py:235-256) is outside this package's scope")
+        """camera.py:235-256: cv.getOptimalNewCameraMatrix(mtx, dist, (w,h), 1, (w,h)), cv.undistort with that
+        matrix, crop to the valid region.  Both OpenCV calls are libcamsync_hip entry points."""
+        img = np.asarray(img)
+        h, w = img.shape[:2]
+        newcameramtx, roi = _hip.optimal_new_camera_matrix(self.mtx, self.dist, (w, h), 1, (w, h))
+        ctx = _hip.get_context(h, w, 1)
+        dst = ctx.undistort(img, self.mtx, self.dist, newcameramtx)
+        x, y, w, h = roi
+        return dst[y : y + h, x : x + w]

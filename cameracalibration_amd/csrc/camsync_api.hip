@@ -44,6 +44,13 @@ struct camsync_ctx {
     size_t poseCap = 0;  // frames the pose scratch is sized for
     int poseN = 0;
 
+    // undistortion: the map of the last (camera, new camera, size) and the output staging (both allocated on first use)
+    uint2* d_umap = nullptr;
+    size_t umapPx = 0;
+    double umapKey[9 + 9 + 8] = {};
+    int umapH = 0, umapW = 0;
+    uint8_t* d_uout = nullptr;
+
     // last detect chunk (for the debug getters)
     int lastB = 0, lastH = 0, lastW = 0;
 
@@ -493,7 +500,7 @@ void camsync_destroy(camsync_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DetBuffers& b = c->buf;
-    void* ptrs[] = {c->d_in, c->d_bin, b.planes, b.gray, b.cand, b.candLong, b.contours, b.pool, b.tasks, b.ckpt, b.chain, b.copies, b.quads, b.qcount, b.counters, b.markers,
+    void* ptrs[] = {c->d_umap, c->d_uout, c->d_in, c->d_bin, b.planes, b.gray, b.cand, b.candLong, b.contours, b.pool, b.tasks, b.ckpt, b.chain, b.copies, b.quads, b.qcount, b.counters, b.markers,
                     b.outIds, b.outCorners, b.rawCorners, b.outCounts, b.outRejected, b.outRejCounts, c->d_dict, c->d_expTab,
                     c->d_obj, c->d_img, c->d_npts, c->d_K, c->d_dist, c->d_rvec, c->d_tvec, c->d_mae, c->d_rmse, c->d_ok,
                     c->d_anchorIds, c->d_anchorObj, c->d_calObj, c->d_calImg, c->cal.intr, c->cal.ext, c->cal.intrTrial,
@@ -1039,6 +1046,72 @@ int camsync_ippe_square_batch(camsync_ctx* c, const float* corners, const double
     HIPCHK(c, hipMemcpyAsync(rvec, c->d_rvec, sizeof(double) * 3 * B, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(tvec, c->d_tvec, sizeof(double) * 3 * B, hipMemcpyDeviceToHost, c->stream));
     if (ok) HIPCHK(c, hipMemcpyAsync(ok, c->d_ok, B, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return CAMSYNC_OK;
+}
+
+/* ---- undistortion ---- */
+
+int camsync_optimal_new_camera_matrix(const double* K, const double* dist, int ndist, int W, int H, double alpha,
+                                      int new_w, int new_h, double* new_K, int32_t* roi) {
+    if (!K || !new_K || W < 2 || H < 2 || ndist < 0 || ndist > 8 || (ndist > 0 && !dist)) return CAMSYNC_E_ARG;
+    double k[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < ndist; i++) k[i] = dist[i];
+    if (new_w <= 0 || new_h <= 0) { new_w = W; new_h = H; }
+    optimal_new_camera_matrix(K, k, W, H, alpha, new_w, new_h, new_K, roi);
+    return CAMSYNC_OK;
+}
+
+int camsync_undistort_batch(camsync_ctx* c, const uint8_t* frames, int on_device, int B, int H, int W, int C,
+                            const double* K, const double* dist, int ndist, const double* new_K, uint8_t* out) {
+    if (!c) return CAMSYNC_E_ARG;
+    if (!frames || !out || B <= 0) return fail(c, CAMSYNC_E_ARG, "frames / out is NULL or batch <= 0");
+    if (C != 1 && C != 3) return fail(c, CAMSYNC_E_ARG, "channels must be 1 or 3, got %d", C);
+    if (H > c->maxH || W > c->maxW || H < 2 || W < 4 || (W % 4))
+        return fail(c, CAMSYNC_E_ARG, "frame %dx%d outside the context's range, or width not a multiple of 4", H, W);
+    if (!K || ndist < 0 || ndist > 8 || (ndist > 0 && !dist)) return fail(c, CAMSYNC_E_ARG, "camera matrix / distortion missing (ndist 0..8)");
+    if (on_device && ((((uintptr_t)frames) | ((uintptr_t)out)) % 4)) return fail(c, CAMSYNC_E_ARG, "device frames must be 4-byte aligned");
+    HIPCHK(c, hipSetDevice(c->device));
+    double key[26];
+    for (int i = 0; i < 9; i++) { key[i] = K[i]; key[9 + i] = new_K ? new_K[i] : K[i]; }
+    for (int i = 0; i < 8; i++) key[18 + i] = i < ndist ? dist[i] : 0.0;
+    if (!undistort_camera_ok(key + 9)) return fail(c, CAMSYNC_E_NUMERIC, "the new camera matrix is singular");
+    const size_t px = (size_t)H * W;
+    if (c->umapPx < px) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->d_umap) (void)hipFree(c->d_umap);
+        c->d_umap = nullptr;
+        c->umapPx = 0;
+        HIPCHK(c, dalloc(&c->d_umap, px));
+        c->umapPx = px;
+        c->umapH = 0;
+    }
+    if (c->umapH != H || c->umapW != W || memcmp(key, c->umapKey, sizeof key) != 0) {
+        launch_undistort_map(key, key + 9, key + 18, H, W, c->d_umap, c->stream);
+        HIPCHK(c, hipGetLastError());
+        memcpy(c->umapKey, key, sizeof key);
+        c->umapH = H;
+        c->umapW = W;
+    }
+    if (!on_device) {
+        int rc = ensure_staging(c);
+        if (rc) return rc;
+        if (!c->d_uout) HIPCHK(c, dalloc(&c->d_uout, (size_t)c->maxB * c->maxH * c->maxW * 3));
+    }
+    for (int b0 = 0; b0 < B; b0 += c->maxB) {
+        const int nb = std::min(c->maxB, B - b0);
+        const uint8_t* src = frames + (size_t)b0 * px * C;
+        uint8_t* dst = out + (size_t)b0 * px * C;
+        if (!on_device) {
+            HIPCHK(c, hipMemcpyAsync(c->d_in, src, (size_t)nb * px * C, hipMemcpyHostToDevice, c->stream));
+            launch_remap(c->d_in, c->d_umap, c->d_uout, nb, H, W, C, c->stream);
+            HIPCHK(c, hipGetLastError());
+            HIPCHK(c, hipMemcpyAsync(dst, c->d_uout, (size_t)nb * px * C, hipMemcpyDeviceToHost, c->stream));
+        } else {
+            launch_remap(src, c->d_umap, dst, nb, H, W, C, c->stream);
+            HIPCHK(c, hipGetLastError());
+        }
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return CAMSYNC_OK;
 }

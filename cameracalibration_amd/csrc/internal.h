@@ -235,6 +235,13 @@ void launch_gather_anchors(const int32_t* ids, const float* corners, const int32
 void launch_ippe(const float* corners, const double* size, int B, const double* K, const double* dist,
                  int ndist, int perFrameCam, double* rvec, double* tvec, uint8_t* ok, hipStream_t st);
 
+// undistortion (k_undistort.hip)
+void optimal_new_camera_matrix(const double* K, const double* k8, int W, int H, double alpha, int newW, int newH,
+                               double* newK, int32_t* roi);
+bool undistort_camera_ok(const double* newK);
+void launch_undistort_map(const double* K, const double* newK, const double* k8, int H, int W, uint2* map, hipStream_t st);
+void launch_remap(const uint8_t* src, const uint2* map, uint8_t* dst, int B, int H, int W, int C, hipStream_t st);
+
 // calibration
 struct CalibState {
     int V, P, NI;          // local views, points per view, active intrinsics (9 or 12)

@@ -215,6 +215,21 @@ int camsync_detect_pnp_resident(camsync_ctx* ctx, const uint8_t* d_frames, int B
                                 int max_markers, int32_t* d_ids, float* d_corners, int32_t* d_counts,
                                 double* d_rvec, double* d_tvec, uint8_t* d_pose_ok);
 
+/* ---- undistortion --------------------------------------------------- */
+
+/* cv.getOptimalNewCameraMatrix(K, dist, (W,H), alpha, (new_w,new_h)) with centerPrincipalPoint = false
+ * (camera.py:246-248; the reference passes alpha = 1 and the same size).  Host arithmetic, no context needed.
+ * new_K f64 [9]; roi (may be NULL) = x, y, w, h of validPixROI.  new_w / new_h <= 0 mean W / H. */
+int camsync_optimal_new_camera_matrix(const double* K, const double* dist, int ndist, int W, int H, double alpha,
+                                      int new_w, int new_h, double* new_K, int32_t* roi);
+
+/* cv.undistort(img, K, dist, None, new_K) (camera.py:251) for B frames of one camera: frames / out u8 [B,H,W,C],
+ * C in {1,3}, W a multiple of 4, both on the host or (on_device) both on the GPU; new_K NULL = K.  Bilinear with
+ * OpenCV's 5 fractional bits and constant (0) border.  The map of the last (K, dist, new_K, size) is kept in the
+ * context, so a stream of frames from one camera pays for it once. */
+int camsync_undistort_batch(camsync_ctx* ctx, const uint8_t* frames, int on_device, int B, int H, int W, int C,
+                            const double* K, const double* dist, int ndist, const double* new_K, uint8_t* out);
+
 /* ---- calibration ---------------------------------------------------- */
 
 /* cv.calibrateCamera(objpoints, imgpoints, size, None, None)

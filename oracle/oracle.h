@@ -145,6 +145,13 @@ double orc_calib_step(void* h, const double* delta);
 void orc_calib_accept(void* h);
 void orc_calib_get(void* h, double intr[12], double* rvecs, double* tvecs);
 
+/* Camera.undistort (reference camera_sync/camera.py:245-255): cv.getOptimalNewCameraMatrix and cv.undistort
+ * (oracle/undistort.cpp).  PARITY UNPINNED: the reference holds no output of either. */
+int orc_optimal_new_camera_matrix(const double* K, const double* dist, int ndist, int W, int H, double alpha, int newW,
+                                  int newH, double* newK, int32_t* roi);
+int orc_undistort(const uint8_t* src, int H, int W, int C, const double* K, const double* dist, int ndist,
+                  const double* newK, uint8_t* dst);
+
 #ifdef __cplusplus
 }
 #endif

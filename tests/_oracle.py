@@ -234,3 +234,24 @@ class CalibShare:
         intr = np.zeros(12); rv = np.zeros((max(self.V, 1), 3)); tv = np.zeros((max(self.V, 1), 3))
         lib().orc_calib_get(self._h, _p(intr), _p(rv), _p(tv))
         return intr, rv[:self.V], tv[:self.V]
+
+
+def optimal_new_camera_matrix(K, dist, image_size, alpha, new_size=None):
+    K = np.ascontiguousarray(K, np.float64).reshape(3, 3); d = np.ascontiguousarray(dist, np.float64).ravel()[:8].copy()
+    w, h = image_size
+    nw, nh = new_size if new_size is not None else (w, h)
+    new_K = np.zeros((3, 3)); roi = np.zeros(4, np.int32)
+    lib().orc_optimal_new_camera_matrix(_p(K), _p(d), len(d), int(w), int(h), C.c_double(alpha), int(nw), int(nh), _p(new_K), _p(roi))
+    return new_K, tuple(int(v) for v in roi)
+
+
+def undistort(img, K, dist, new_K=None):
+    src = np.ascontiguousarray(img, np.uint8)
+    h, w = src.shape[:2]
+    c = 1 if src.ndim == 2 else src.shape[2]
+    K = np.ascontiguousarray(K, np.float64).reshape(3, 3); d = np.ascontiguousarray(dist, np.float64).ravel()[:8].copy()
+    nk = None if new_K is None else np.ascontiguousarray(new_K, np.float64).reshape(3, 3)
+    out = np.empty_like(src)
+    rc = lib().orc_undistort(_p(src), h, w, c, _p(K), _p(d), len(d), _p(nk) if nk is not None else None, _p(out))
+    assert rc == 0
+    return out
