@@ -111,6 +111,33 @@ def compare_with_oracle(res, ids, cor, cnt, ok, rv, tv):
             "frames_pose_above_1e-6_rel": int(bad_pose), "max_corner_err_px": worst_c, "max_pose_rel_err": worst_p}
 
 
+def run_configs0():
+    """BASELINE configs[0]: Camera.calibrate on the reference's nine 640x480 chessboard photos (tests/golden/calib,
+    copies of pics/calib) -- corner candidates, cornerSubPix and the calibrateCamera LM on the GPU, no cv2 -- compared
+    with the calibration the reference stores for them (calibration/robot_640-480_500.npz)."""
+    try:
+        import contextlib
+        import io
+        from PIL import Image
+        from cameracalibration_amd.camera_sync.camera import Camera
+        from tests import _data
+        frames = []
+        for i in range(1, 10):
+            rgb = np.array(Image.open(os.path.join(_data.GOLDEN, "calib", "frame%d.jpg" % i)).convert("RGB"))
+            frames.append(np.ascontiguousarray(rgb[:, :, ::-1]))
+        with contextlib.redirect_stdout(io.StringIO()):  # the reference prints progress; stdout carries the JSON line
+            Camera.calibrate(frames, (7, 7))
+            t0 = time.perf_counter()
+            mtx, dist = Camera.calibrate(frames, (7, 7))
+            dt = time.perf_counter() - t0
+        ref_K, ref_d = _data.calibration("robot_640-480_500.npz")
+        return {"ran": True, "frames": len(frames), "seconds": dt, "fx": float(mtx[0, 0]), "fy": float(mtx[1, 1]),
+                "max_abs_diff_mtx_vs_reference_npz": float(np.abs(mtx - ref_K).max()),
+                "max_abs_diff_dist_vs_reference_npz": float(np.abs(dist.ravel() - ref_d.ravel()).max())}
+    except Exception as e:
+        return {"ran": False, "error": "%s: %s" % (type(e).__name__, e)}
+
+
 def launch_ranks(n, argv):
     """Start n ranks of this script (one process per GPU) and wait for them.  The parent never touches a GPU: the
     children are started before any torch / HIP call, with RANK, LOCAL_RANK, WORLD_SIZE and the rendezvous address in
@@ -364,8 +391,8 @@ def main():
                          "pipeline_frac_k1k3": (ALG_BYTES_PER_PX_K1K3 * H * W * value / max(world, 1)) / 1e9 / HBM_PEAK_GBS},
             "stage_ms_per_step": stage_ms,
             "check": {"frames_with_pose": n_ok, "mean_markers_per_frame": mean_markers},
-            "configs0": "skipped: cv2 unavailable (Camera.calibrate on pics/calib is the reference's OpenCV CPU path)",
         }
+        out["configs0"] = run_configs0()
         if not args.no_cpu and world == 1:
             threads = max(1, min(16, len(os.sched_getaffinity(0))))
             ns = min(args.cpu_sample, B)

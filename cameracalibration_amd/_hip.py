@@ -109,6 +109,8 @@ def load_library() -> C.CDLL:
         lib.camsync_detect_pnp_frames.argtypes = lib.camsync_detect_pnp_batch.argtypes
         lib.camsync_detect_pnp_resident.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, i32, vp, vp, i32,
                                                     i32, vp, vp, vp, vp, vp, vp]
+        lib.camsync_chess_candidates.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp]
+        lib.camsync_corner_subpix.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, i32, i32, dbl, vp]
         lib.camsync_optimal_new_camera_matrix.argtypes = [vp, vp, i32, i32, i32, dbl, i32, i32, vp, vp]
         lib.camsync_undistort_batch.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp]
         lib.camsync_calibrate.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp]
@@ -375,6 +377,27 @@ class Context:
             self._h, C.c_void_p(d_frames_ptr), B, H, W, Cn, _ptr(anchor_ids), _ptr(anchor_obj), len(anchor_ids),
             _ptr(K), _ptr(d), d.shape[1], max_markers, C.c_void_p(d_ids), C.c_void_p(d_corners), C.c_void_p(d_counts),
             C.c_void_p(d_rvec), C.c_void_p(d_tvec), C.c_void_p(d_ok)))
+
+    # -- chessboard front end ------------------------------------------
+    def chess_candidates(self, frames, scale=1, max_cand=1024):
+        """X-corner candidates per frame, strongest first: list of (xy int32 [n,2], strength int32 [n])."""
+        f = self._frames(frames)
+        B, H, W, Cn = f.shape
+        xy = np.zeros((B, max_cand, 2), np.int32); st = np.zeros((B, max_cand), np.int32); cnt = np.zeros(B, np.int32)
+        self._check(self._lib.camsync_chess_candidates(self._h, _ptr(f), 0, B, H, W, Cn, scale, max_cand, _ptr(xy), _ptr(st), _ptr(cnt)))
+        return [(xy[b, :cnt[b]].copy(), st[b, :cnt[b]].copy()) for b in range(B)]
+
+    def corner_subpix(self, frames, pts, win, max_iter, eps, npts=None):
+        """cv.cornerSubPix for a batch: pts [B,N,2] -> refined [B,N,2] float32."""
+        f = self._frames(frames)
+        B, H, W, Cn = f.shape
+        p = np.ascontiguousarray(pts, dtype=np.float32).reshape(B, -1, 2)
+        N = p.shape[1]
+        n = None if npts is None else np.ascontiguousarray(npts, dtype=np.int32)
+        out = np.zeros_like(p)
+        self._check(self._lib.camsync_corner_subpix(self._h, _ptr(f), 0, B, H, W, Cn, _ptr(p), _ptr(n), N, int(win), int(max_iter),
+                                                    float(eps), _ptr(out)))
+        return out
 
     # -- undistortion --------------------------------------------------
     def undistort(self, frames, K, dist, new_K=None):

@@ -27,13 +27,51 @@ class Camera:
     # -- calibration -----------------------------------------------------------------------
     @staticmethod
     def calibrate(frames, pointsToFind=(7, 7)):
-        """Reference camera.py:23-77 finds chessboard corners in `frames` with OpenCV, then calls
-        cv.calibrateCamera.  The corner finder is not part of this package: find the corners with
-        any detector and call Camera.calibrateFromPoints, which is the cv.calibrateCamera half."""
-        raise NotImplementedError(
-            "chessboard corner detection is outside this package's scope; "
-            "use Camera.calibrateFromPoints(objpoints, imgpoints, image_size)"
-        )
+        """camera.py:23-77: find the chessboard's inner corners in every frame, refine them with
+        cornerSubPix((11,11), (-1,-1), (EPS + MAX_ITER, 30, 0.001)), run cv.calibrateCamera on the frames where the
+        board was found, print the mean reprojection error, return (mtx, dist).
+        Frames are BGR uint8 images of one size; all of them go through the GPU together."""
+        from . import chessboard as cb
+
+        criteria = (cb.TERM_CRITERIA_EPS + cb.TERM_CRITERIA_MAX_ITER, 30, 0.001)
+        objp = Camera.boardPoints(pointsToFind)
+        frames = [np.asarray(f) for f in frames]
+        print("Starting calibration, this may take some time...")
+        found = cb.findChessboardCornersBatch(frames, pointsToFind)
+        keep = [i for i, (ret, _) in enumerate(found) if ret]
+        if not keep:
+            raise _hip.CamsyncError(_hip.E_ARG, "no chessboard found in any frame (cv.calibrateCamera would fail on empty input)")
+        h, w = frames[0].shape[:2]
+        ctx = _hip.get_context(h, w, len(keep))
+        batch = np.stack([frames[i] if frames[i].ndim == 3 else frames[i][..., None] for i in keep])
+        start = np.stack([found[i][1].reshape(-1, 2) for i in keep])
+        refined = ctx.corner_subpix(batch, start, 11, criteria[1], criteria[2])
+        objpoints = [objp for _ in keep]
+        imgpoints = [r.reshape(-1, 1, 2) for r in refined]
+        rms, mtx, dist, rvecs, tvecs = Camera.calibrateFromPoints(objpoints, imgpoints, (w, h), returnAll=True)
+        mean_error = 0.0
+        for obj, img, rv, tv in zip(objpoints, imgpoints, rvecs, tvecs):
+            proj = Camera.projectPoints(obj, rv, tv, mtx, dist)
+            mean_error += float(np.sqrt(((img.reshape(-1, 2) - proj) ** 2).sum())) / len(proj)  # cv.norm(L2) / N
+        print("total error: {}".format(mean_error / len(objpoints)))
+        return mtx, dist
+
+    @staticmethod
+    def projectPoints(objpoints, rvec, tvec, mtx, dist) -> np.ndarray:
+        """cv.projectPoints (camera.py:67-69) on the host, for the printed evaluation only: [N,2] float64."""
+        from .referential import rodrigues_to_matrix
+
+        X = np.asarray(objpoints, np.float64).reshape(-1, 3) @ rodrigues_to_matrix(rvec).T + np.asarray(tvec, np.float64).reshape(3)
+        x, y = X[:, 0] / X[:, 2], X[:, 1] / X[:, 2]
+        k = np.zeros(8)
+        d = np.asarray(dist, np.float64).ravel()[:8]
+        k[:d.size] = d
+        r2 = x * x + y * y
+        rad = (1 + k[0] * r2 + k[1] * r2 ** 2 + k[4] * r2 ** 3) / (1 + k[5] * r2 + k[6] * r2 ** 2 + k[7] * r2 ** 3)
+        xd = x * rad + 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x)
+        yd = y * rad + k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y
+        mtx = np.asarray(mtx, np.float64)
+        return np.stack([mtx[0, 0] * xd + mtx[0, 2], mtx[1, 1] * yd + mtx[1, 2]], axis=1)
 
     @staticmethod
     def boardPoints(pointsToFind=(7, 7)) -> np.ndarray:

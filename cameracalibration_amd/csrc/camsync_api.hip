@@ -51,6 +51,15 @@ struct camsync_ctx {
     int umapH = 0, umapW = 0;
     uint8_t* d_uout = nullptr;
 
+    // chessboard candidates / cornerSubPix on points: scratch for chunks of chessChunk frames (allocated on first use)
+    int chessChunk = 0, chessMaxCand = 0, subpixCap = 0;
+    uint8_t* d_chessGray = nullptr;
+    uint16_t* d_chessS = nullptr;
+    int32_t *d_chessR = nullptr, *d_chessCand = nullptr;
+    int *d_chessMax = nullptr, *d_chessCount = nullptr;
+    float *d_spIn = nullptr, *d_spOut = nullptr;
+    int32_t* d_spN = nullptr;
+
     // last detect chunk (for the debug getters)
     int lastB = 0, lastH = 0, lastW = 0;
 
@@ -500,7 +509,8 @@ void camsync_destroy(camsync_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DetBuffers& b = c->buf;
-    void* ptrs[] = {c->d_umap, c->d_uout, c->d_in, c->d_bin, b.planes, b.gray, b.cand, b.candLong, b.contours, b.pool, b.tasks, b.ckpt, b.chain, b.copies, b.quads, b.qcount, b.counters, b.markers,
+    void* ptrs[] = {c->d_chessGray, c->d_chessS, c->d_chessR, c->d_chessCand, c->d_chessMax, c->d_chessCount, c->d_spIn, c->d_spOut, c->d_spN,
+                    c->d_umap, c->d_uout, c->d_in, c->d_bin, b.planes, b.gray, b.cand, b.candLong, b.contours, b.pool, b.tasks, b.ckpt, b.chain, b.copies, b.quads, b.qcount, b.counters, b.markers,
                     b.outIds, b.outCorners, b.rawCorners, b.outCounts, b.outRejected, b.outRejCounts, c->d_dict, c->d_expTab,
                     c->d_obj, c->d_img, c->d_npts, c->d_K, c->d_dist, c->d_rvec, c->d_tvec, c->d_mae, c->d_rmse, c->d_ok,
                     c->d_anchorIds, c->d_anchorObj, c->d_calObj, c->d_calImg, c->cal.intr, c->cal.ext, c->cal.intrTrial,
@@ -1047,6 +1057,118 @@ int camsync_ippe_square_batch(camsync_ctx* c, const float* corners, const double
     HIPCHK(c, hipMemcpyAsync(tvec, c->d_tvec, sizeof(double) * 3 * B, hipMemcpyDeviceToHost, c->stream));
     if (ok) HIPCHK(c, hipMemcpyAsync(ok, c->d_ok, B, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return CAMSYNC_OK;
+}
+
+/* ---- chessboard front end ---- */
+
+int camsync_chess_candidates(camsync_ctx* c, const uint8_t* frames, int on_device, int B, int H, int W, int C, int scale,
+                             int max_cand, int32_t* xy, int32_t* strength, int32_t* counts) {
+    if (!c) return CAMSYNC_E_ARG;
+    if (!frames || B <= 0 || !xy || !strength || !counts) return fail(c, CAMSYNC_E_ARG, "missing argument");
+    if (C != 1 && C != 3) return fail(c, CAMSYNC_E_ARG, "channels must be 1 or 3, got %d", C);
+    if (scale < 1 || scale > 16 || max_cand < 1 || max_cand > 65536) return fail(c, CAMSYNC_E_ARG, "scale must be 1..16, max_cand 1..65536");
+    if (H > c->maxH || W > c->maxW || H <= 10 * scale || W <= 10 * scale)
+        return fail(c, CAMSYNC_E_ARG, "frame %dx%d outside the context's range, or smaller than the detector's ring", H, W);
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t px = (size_t)H * W, maxPx = (size_t)c->maxH * c->maxW;
+    if (!c->chessChunk) {
+        const int chunk = std::min(c->maxB, 16);
+        HIPCHK(c, dalloc(&c->d_chessGray, chunk * maxPx));
+        HIPCHK(c, dalloc(&c->d_chessS, chunk * maxPx));
+        HIPCHK(c, dalloc(&c->d_chessR, chunk * maxPx));
+        HIPCHK(c, dalloc(&c->d_chessMax, (size_t)chunk));
+        HIPCHK(c, dalloc(&c->d_chessCount, (size_t)chunk));
+        c->chessChunk = chunk;
+    }
+    if (c->chessMaxCand < max_cand) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->d_chessCand) (void)hipFree(c->d_chessCand);
+        c->d_chessCand = nullptr;
+        c->chessMaxCand = 0;
+        HIPCHK(c, dalloc(&c->d_chessCand, (size_t)c->chessChunk * max_cand * 3));
+        c->chessMaxCand = max_cand;
+    }
+    if (!on_device) {
+        int rc = ensure_staging(c);
+        if (rc) return rc;
+    }
+    std::vector<int32_t> hc((size_t)c->chessChunk * max_cand * 3);
+    std::vector<int> hn(c->chessChunk);
+    struct Cd { int32_t x, y, v; };
+    for (int b0 = 0; b0 < B; b0 += c->chessChunk) {
+        const int nb = std::min(c->chessChunk, B - b0);
+        const uint8_t* src = frames + (size_t)b0 * px * C;
+        if (!on_device) {
+            HIPCHK(c, hipMemcpyAsync(c->d_in, src, (size_t)nb * px * C, hipMemcpyHostToDevice, c->stream));
+            src = c->d_in;
+        }
+        HIPCHK(c, hipMemsetAsync(c->d_chessMax, 0, sizeof(int) * nb, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_chessCount, 0, sizeof(int) * nb, c->stream));
+        launch_chess(src, C, nb, H, W, scale, c->d_chessGray, c->d_chessS, c->d_chessR, c->d_chessMax, max_cand, c->d_chessCand,
+                     c->d_chessCount, c->stream);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(hn.data(), c->d_chessCount, sizeof(int) * nb, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(hc.data(), c->d_chessCand, sizeof(int32_t) * 3 * (size_t)nb * max_cand, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (int f = 0; f < nb; f++) {
+            if (hn[f] > max_cand)
+                return fail(c, CAMSYNC_E_CAPACITY, "frame %d has %d corner candidates, more than max_cand = %d", b0 + f, hn[f], max_cand);
+            Cd* cd = reinterpret_cast<Cd*>(hc.data() + (size_t)f * max_cand * 3);
+            // strongest first; equal strengths in raster order (the kernel appends in no particular order)
+            std::sort(cd, cd + hn[f], [](const Cd& a, const Cd& b) { return a.v != b.v ? a.v > b.v : (a.y != b.y ? a.y < b.y : a.x < b.x); });
+            counts[b0 + f] = hn[f];
+            for (int k = 0; k < hn[f]; k++) {
+                xy[((size_t)(b0 + f) * max_cand + k) * 2] = cd[k].x;
+                xy[((size_t)(b0 + f) * max_cand + k) * 2 + 1] = cd[k].y;
+                strength[(size_t)(b0 + f) * max_cand + k] = cd[k].v;
+            }
+        }
+    }
+    return CAMSYNC_OK;
+}
+
+int camsync_corner_subpix(camsync_ctx* c, const uint8_t* frames, int on_device, int B, int H, int W, int C,
+                          const float* pts, const int32_t* npts, int N, int win, int max_iter, double eps, float* out) {
+    if (!c) return CAMSYNC_E_ARG;
+    if (!frames || !pts || !out || B <= 0 || N <= 0) return fail(c, CAMSYNC_E_ARG, "missing argument");
+    if (C != 1 && C != 3) return fail(c, CAMSYNC_E_ARG, "channels must be 1 or 3, got %d", C);
+    if (H > c->maxH || W > c->maxW || H < 2 || W < 2) return fail(c, CAMSYNC_E_ARG, "frame %dx%d outside the context's range", H, W);
+    if (win < 1 || win > 20) return fail(c, CAMSYNC_E_ARG, "cornerSubPix window half-size must be 1..20, got %d", win);
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t px = (size_t)H * W;
+    const int chunk = c->maxB;
+    if (c->subpixCap < chunk * N) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        (void)hipFree(c->d_spIn); (void)hipFree(c->d_spOut); (void)hipFree(c->d_spN);
+        c->d_spIn = c->d_spOut = nullptr;
+        c->d_spN = nullptr;
+        c->subpixCap = 0;
+        HIPCHK(c, dalloc(&c->d_spIn, (size_t)chunk * N * 2));
+        HIPCHK(c, dalloc(&c->d_spOut, (size_t)chunk * N * 2));
+        HIPCHK(c, dalloc(&c->d_spN, (size_t)chunk));
+        c->subpixCap = chunk * N;
+    }
+    if (!on_device) {
+        int rc = ensure_staging(c);
+        if (rc) return rc;
+    }
+    for (int b0 = 0; b0 < B; b0 += chunk) {
+        const int nb = std::min(chunk, B - b0);
+        const uint8_t* src = frames + (size_t)b0 * px * C;
+        if (!on_device) {
+            HIPCHK(c, hipMemcpyAsync(c->d_in, src, (size_t)nb * px * C, hipMemcpyHostToDevice, c->stream));
+            src = c->d_in;
+        }
+        HIPCHK(c, hipMemcpyAsync(c->d_spIn, pts + (size_t)b0 * N * 2, sizeof(float) * 2 * (size_t)nb * N, hipMemcpyHostToDevice, c->stream));
+        if (npts) HIPCHK(c, hipMemcpyAsync(c->d_spN, npts + b0, sizeof(int32_t) * nb, hipMemcpyHostToDevice, c->stream));
+        // points the kernel skips (beyond npts) come back unchanged
+        HIPCHK(c, hipMemcpyAsync(c->d_spOut, c->d_spIn, sizeof(float) * 2 * (size_t)nb * N, hipMemcpyDeviceToDevice, c->stream));
+        launch_subpix_points(src, C, nb, H, W, c->d_spIn, npts ? c->d_spN : nullptr, N, win, max_iter, eps, c->d_expTab, c->d_spOut, c->stream);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(out + (size_t)b0 * N * 2, c->d_spOut, sizeof(float) * 2 * (size_t)nb * N, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     return CAMSYNC_OK;
 }
 

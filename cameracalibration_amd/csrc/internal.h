@@ -235,6 +235,12 @@ void launch_gather_anchors(const int32_t* ids, const float* corners, const int32
 void launch_ippe(const float* corners, const double* size, int B, const double* K, const double* dist,
                  int ndist, int perFrameCam, double* rvec, double* tvec, uint8_t* ok, hipStream_t st);
 
+// chessboard corner candidates (k_chess.hip) and cornerSubPix on caller-supplied points (k_subpix.hip)
+void launch_chess(const uint8_t* in, int C, int B, int H, int W, int scale, uint8_t* gray, uint16_t* S, int32_t* R,
+                  int* frameMax, int maxCand, int32_t* cand, int* counts, hipStream_t st);
+void launch_subpix_points(const uint8_t* gray, int grayC, int B, int H, int W, const float* pts, const int32_t* npts, int N,
+                          int win, int maxIters, double eps, const float* expTab, float* out, hipStream_t st);
+
 // undistortion (k_undistort.hip)
 void optimal_new_camera_matrix(const double* K, const double* k8, int W, int H, double alpha, int newW, int newH,
                                double* newK, int32_t* roi);

@@ -110,6 +110,95 @@ __device__ __forceinline__ float patch_elem(const GraySrc& src, int W, int H, co
     return src.at(r0 + x0) * g.a11 + src.at(r0 + x0 + 1) * g.a12 + src.at(r1 + x0) * g.a21 + src.at(r1 + x0 + 1) * g.a22;
 }
 
+// cv::cornerSubPix for one corner, by one wavefront: window half-size win (<= kMaxWin), criteria (MAX_ITER | EPS,
+// max_iters, sqrt(eps2)), zero zone off.  s_buf / s_reg are the wave's LDS scratch (kMaxPatch^2 floats,
+// kRegDim^2 bytes).  Every lane returns the refined corner.
+__device__ __forceinline__ void refine_corner(const GraySrc& src, int W, int H, float cTx, float cTy, int win, int max_iters,
+                                              double eps2, const float* __restrict__ expTab, int lane, float* s_buf,
+                                              uint8_t* s_reg, float& outX, float& outY) {
+    const int ww = 2 * win + 1, pw = ww + 2;
+    const float* __restrict__ et = expTab + win * (2 * kMaxWin + 1);
+    // (row, column) of this lane's first element and of a step of 64 elements, for the patch and the window
+    const int pi0 = lane / pw, pj0 = lane - pi0 * pw, pqi = 64 / pw, pqj = 64 - pqi * pw;
+    const int wi0 = lane / ww, wj0 = lane - wi0 * ww, wqi = 64 / ww, wqj = 64 - wqi * ww;
+    float cIx = cTx, cIy = cTy;
+    int iter = 0;
+    double err = 0;
+    // the region around the first patch, clipped to the image
+    const PatchGeom g0 = patch_geom(cIx, cIy, pw, W, H);
+    const int rx0 = max(g0.ipx - kRegMargin, 0), ry0 = max(g0.ipy - kRegMargin, 0);
+    const int rx1 = min(g0.ipx + pw + kRegMargin, W - 1), ry1 = min(g0.ipy + pw + kRegMargin, H - 1);
+    const int rw = rx1 - rx0 + 1, rh = ry1 - ry0 + 1;
+    const bool hasReg = rw > 0 && rh > 0 && rw <= kRegDim && rh <= kRegDim;
+    __syncthreads();
+    if (hasReg) {
+        const int qi = 64 / rw, qj = 64 - qi * rw;
+        for (int e = lane, i = lane / rw, j = lane - (lane / rw) * rw; e < rw * rh; e += 64) {
+            s_reg[e] = (uint8_t)src.at((size_t)(ry0 + i) * W + rx0 + j);
+            i += qi;
+            j += qj;
+            if (j >= rw) { j -= rw; i++; }
+        }
+    }
+    do {
+        const PatchGeom g = patch_geom(cIx, cIy, pw, W, H);
+        __syncthreads();
+        // element e = lane + 64 k of the patch is (row, column) = (i, j); stepping by 64 elements without dividing
+        if (hasReg && g.fast && g.ipx >= rx0 && g.ipx + pw <= rx1 && g.ipy >= ry0 && g.ipy + pw <= ry1) {
+            const uint8_t* rp = s_reg + (g.ipy - ry0) * rw + (g.ipx - rx0);
+            for (int e = lane, i = pi0, j = pj0; e < pw * pw; e += 64) {
+                s_buf[e] = patch_elem_inside(rp + i * rw, rw, g, j);
+                i += pqi;
+                j += pqj;
+                if (j >= pw) { j -= pw; i++; }
+            }
+        } else {
+            for (int e = lane, i = pi0, j = pj0; e < pw * pw; e += 64) {
+                s_buf[e] = patch_elem(src, W, H, g, i, j);
+                i += pqi;
+                j += pqj;
+                if (j >= pw) { j -= pw; i++; }
+            }
+        }
+        __syncthreads();
+        double a = 0, b = 0, c = 0, bb1 = 0, bb2 = 0;
+        for (int e = lane, i = wi0, j = wj0; e < ww * ww; e += 64, i += wqi, j += wqj) {
+            if (j >= ww) { j -= ww; i++; }
+            const float* sp = s_buf + (i + 1) * pw + (j + 1);
+            const double m = (double)(float)(et[i] * et[j]);
+            const double tgx = (double)(sp[1] - sp[-1]);
+            const double tgy = (double)(sp[pw] - sp[-pw]);
+            const double gxx = tgx * tgx * m, gxy = tgx * tgy * m, gyy = tgy * tgy * m;
+            const double px = j - win, py = i - win;
+            a += gxx;
+            b += gxy;
+            c += gyy;
+            bb1 += gxx * px + gxy * py;
+            bb2 += gxy * px + gyy * py;
+        }
+        a = wave_sum_d(a);
+        b = wave_sum_d(b);
+        c = wave_sum_d(c);
+        bb1 = wave_sum_d(bb1);
+        bb2 = wave_sum_d(bb2);
+        const double det = a * c - b * b;
+        if (fabs(det) <= 2.220446049250313e-16 * 2.220446049250313e-16) break;
+        const double scale = 1.0 / det;
+        const float nx = (float)(cIx + c * scale * bb1 - b * scale * bb2);
+        const float ny = (float)(cIy - b * scale * bb1 + a * scale * bb2);
+        err = (double)((nx - cIx) * (nx - cIx) + (ny - cIy) * (ny - cIy));
+        cIx = nx;
+        cIy = ny;
+        if (cIx < 0 || cIx >= W || cIy < 0 || cIy >= H) break;
+    } while (++iter < max_iters && err > eps2);
+    if (fabsf(cIx - cTx) > win || fabsf(cIy - cTy) > win) {
+        cIx = cTx;
+        cIy = cTy;
+    }
+    outX = cIx;
+    outY = cIy;
+}
+
 __global__ __launch_bounds__(64) void k_subpix(const uint8_t* __restrict__ gray, int grayC, const MarkerRec* __restrict__ markers,
                                                unsigned int markerCap, const Counters* __restrict__ ctr,
                                                const float* __restrict__ rawCorners, float* __restrict__ outCorners,
@@ -135,94 +224,37 @@ __global__ __launch_bounds__(64) void k_subpix(const uint8_t* __restrict__ gray,
         int win = max(1, (int)rint((double)(cfg.relWin * ms)));
         win = min(win, cfg.subpixWin);
         win = min(win, kMaxWin);
-        const int ww = 2 * win + 1, pw = ww + 2;
-        const float* __restrict__ et = expTab + win * (2 * kMaxWin + 1);
         const int max_iters = min(max(cfg.subpixMaxIter, 1), 100);
         double eps = fmax(cfg.subpixEps, 0.);
         eps *= eps;
-
-        // (row, column) of this lane's first element and of a step of 64 elements, for the patch and the window
-        const int pi0 = lane / pw, pj0 = lane - pi0 * pw, pqi = 64 / pw, pqj = 64 - pqi * pw;
-        const int wi0 = lane / ww, wj0 = lane - wi0 * ww, wqi = 64 / ww, wqj = 64 - wqi * ww;
-        const float cTx = mc[2 * corner], cTy = mc[2 * corner + 1];
-        float cIx = cTx, cIy = cTy;
-        int iter = 0;
-        double err = 0;
-        // the region around the first patch, clipped to the image
-        const PatchGeom g0 = patch_geom(cIx, cIy, pw, W, H);
-        const int rx0 = max(g0.ipx - kRegMargin, 0), ry0 = max(g0.ipy - kRegMargin, 0);
-        const int rx1 = min(g0.ipx + pw + kRegMargin, W - 1), ry1 = min(g0.ipy + pw + kRegMargin, H - 1);
-        const int rw = rx1 - rx0 + 1, rh = ry1 - ry0 + 1;
-        const bool hasReg = rw > 0 && rh > 0 && rw <= kRegDim && rh <= kRegDim;
-        __syncthreads();
-        if (hasReg) {
-            const int qi = 64 / rw, qj = 64 - qi * rw;
-            for (int e = lane, i = lane / rw, j = lane - (lane / rw) * rw; e < rw * rh; e += 64) {
-                s_reg[e] = (uint8_t)src.at((size_t)(ry0 + i) * W + rx0 + j);
-                i += qi;
-                j += qj;
-                if (j >= rw) { j -= rw; i++; }
-            }
-        }
-        do {
-            const PatchGeom g = patch_geom(cIx, cIy, pw, W, H);
-            __syncthreads();
-            // element e = lane + 64 k of the patch is (row, column) = (i, j); stepping by 64 elements without dividing
-            if (hasReg && g.fast && g.ipx >= rx0 && g.ipx + pw <= rx1 && g.ipy >= ry0 && g.ipy + pw <= ry1) {
-                const uint8_t* rp = s_reg + (g.ipy - ry0) * rw + (g.ipx - rx0);
-                for (int e = lane, i = pi0, j = pj0; e < pw * pw; e += 64) {
-                    s_buf[e] = patch_elem_inside(rp + i * rw, rw, g, j);
-                    i += pqi;
-                    j += pqj;
-                    if (j >= pw) { j -= pw; i++; }
-                }
-            } else {
-                for (int e = lane, i = pi0, j = pj0; e < pw * pw; e += 64) {
-                    s_buf[e] = patch_elem(src, W, H, g, i, j);
-                    i += pqi;
-                    j += pqj;
-                    if (j >= pw) { j -= pw; i++; }
-                }
-            }
-            __syncthreads();
-            double a = 0, b = 0, c = 0, bb1 = 0, bb2 = 0;
-            for (int e = lane, i = wi0, j = wj0; e < ww * ww; e += 64, i += wqi, j += wqj) {
-                if (j >= ww) { j -= ww; i++; }
-                const float* sp = s_buf + (i + 1) * pw + (j + 1);
-                const double m = (double)(float)(et[i] * et[j]);
-                const double tgx = (double)(sp[1] - sp[-1]);
-                const double tgy = (double)(sp[pw] - sp[-pw]);
-                const double gxx = tgx * tgx * m, gxy = tgx * tgy * m, gyy = tgy * tgy * m;
-                const double px = j - win, py = i - win;
-                a += gxx;
-                b += gxy;
-                c += gyy;
-                bb1 += gxx * px + gxy * py;
-                bb2 += gxy * px + gyy * py;
-            }
-            a = wave_sum_d(a);
-            b = wave_sum_d(b);
-            c = wave_sum_d(c);
-            bb1 = wave_sum_d(bb1);
-            bb2 = wave_sum_d(bb2);
-            const double det = a * c - b * b;
-            if (fabs(det) <= 2.220446049250313e-16 * 2.220446049250313e-16) break;
-            const double scale = 1.0 / det;
-            const float nx = (float)(cIx + c * scale * bb1 - b * scale * bb2);
-            const float ny = (float)(cIy - b * scale * bb1 + a * scale * bb2);
-            err = (double)((nx - cIx) * (nx - cIx) + (ny - cIy) * (ny - cIy));
-            cIx = nx;
-            cIy = ny;
-            if (cIx < 0 || cIx >= W || cIy < 0 || cIy >= H) break;
-        } while (++iter < max_iters && err > eps);
-        if (fabsf(cIx - cTx) > win || fabsf(cIy - cTy) > win) {
-            cIx = cTx;
-            cIy = cTy;
-        }
+        float cIx, cIy;
+        refine_corner(src, W, H, mc[2 * corner], mc[2 * corner + 1], win, max_iters, eps, expTab, lane, s_buf, s_reg, cIx, cIy);
         if (lane == 0) {
             float* dst = outCorners + ((size_t)mr.frame * kMaxMarkerOut + mr.slot) * 8;
             dst[2 * corner] = cIx;
             dst[2 * corner + 1] = cIy;
+        }
+    }
+}
+
+// cv.cornerSubPix on caller-supplied points: pts / out f32 [B,N,2], npts [B] (null: N each); one wave per point
+__global__ __launch_bounds__(64) void k_subpix_points(const uint8_t* __restrict__ gray, int grayC, int B, int H, int W,
+                                                      const float* __restrict__ pts, const int32_t* __restrict__ npts, int N,
+                                                      int win, int maxIters, double eps2, const float* __restrict__ expTab,
+                                                      float* __restrict__ out) {
+    __shared__ float s_buf[kMaxPatch * kMaxPatch];
+    __shared__ uint8_t s_reg[kRegDim * kRegDim];
+    const int lane = threadIdx.x;
+    const unsigned int total = (unsigned int)B * (unsigned int)N;
+    for (unsigned int job = blockIdx.x; job < total; job += gridDim.x) {
+        const unsigned int f = job / (unsigned int)N, k = job - f * (unsigned int)N;
+        if (npts && (int)k >= npts[f]) continue;  // (uniform: the whole wave works on one job)
+        const GraySrc src{gray + (size_t)f * H * W * grayC, grayC, (uint32_t)(H * W - 1)};
+        float cx, cy;
+        refine_corner(src, W, H, pts[2 * (size_t)job], pts[2 * (size_t)job + 1], win, maxIters, eps2, expTab, lane, s_buf, s_reg, cx, cy);
+        if (lane == 0) {
+            out[2 * (size_t)job] = cx;
+            out[2 * (size_t)job + 1] = cy;
         }
     }
 }
@@ -235,6 +267,14 @@ void launch_subpix(const DetCfg& c, const DetBuffers& b, int B, hipStream_t st) 
     const unsigned blocks = (unsigned)std::min(std::max(B * 32, 64), 256 * 128);
     hipLaunchKernelGGL(k_subpix, dim3(blocks), dim3(64), 0, st, b.graySrc, b.graySrcC, b.markers, b.markerCap, b.counters,
                        b.rawCorners, b.outCorners, b.expTab, c);
+}
+
+void launch_subpix_points(const uint8_t* gray, int grayC, int B, int H, int W, const float* pts, const int32_t* npts, int N,
+                          int win, int maxIters, double eps, const float* expTab, float* out, hipStream_t st) {
+    const unsigned total = (unsigned)B * (unsigned)N;
+    if (!total) return;
+    hipLaunchKernelGGL(k_subpix_points, dim3(std::min(total, 256u * 64u)), dim3(64), 0, st, gray, grayC, B, H, W, pts, npts, N,
+                       std::min(std::max(win, 1), kMaxWin), std::min(std::max(maxIters, 1), 100), eps * eps, expTab, out);
 }
 
 }  // namespace camsync

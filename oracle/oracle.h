@@ -152,6 +152,10 @@ int orc_optimal_new_camera_matrix(const double* K, const double* dist, int ndist
 int orc_undistort(const uint8_t* src, int H, int W, int C, const double* K, const double* dist, int ndist,
                   const double* newK, uint8_t* dst);
 
+/* CPU twin of this repository's chessboard corner-candidate stage (oracle/chessboard.cpp; NOT a restatement of
+ * cv.findChessboardCorners, see that file). */
+int orc_chess_candidates(const uint8_t* gray, int H, int W, int scale, int max_cand, int32_t* xy, int32_t* strength);
+
 #ifdef __cplusplus
 }
 #endif

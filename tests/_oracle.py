@@ -255,3 +255,12 @@ def undistort(img, K, dist, new_K=None):
     rc = lib().orc_undistort(_p(src), h, w, c, _p(K), _p(d), len(d), _p(nk) if nk is not None else None, _p(out))
     assert rc == 0
     return out
+
+
+def chess_candidates(gray, scale=1, max_cand=4096):
+    g = np.ascontiguousarray(gray, np.uint8)
+    h, w = g.shape
+    xy = np.zeros((max_cand, 2), np.int32); st = np.zeros(max_cand, np.int32)
+    n = lib().orc_chess_candidates(_p(g), h, w, int(scale), max_cand, _p(xy), _p(st))
+    assert n <= max_cand
+    return xy[:n], st[:n]

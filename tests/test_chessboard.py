@@ -1,0 +1,147 @@
+"""Camera.calibrate's front end (reference camera_sync/camera.py:48-63): chessboard corners, cornerSubPix((11,11)),
+calibrateCamera.
+
+PIN P5.  The reference ships nine chessboard photos (pics/calib/frame1..9.jpg, copied to tests/golden/calib/ as
+input data) and eight stored calibrations.  Running the photos through corner candidates -> lattice -> cornerSubPix
+-> calibrateCamera reproduces calibration/robot_640-480_500.npz: focal lengths to 1e-5 relative, principal point to
+0.01 px, distortion to 2e-4.  That ties the calibration solver (K12, until now "parity unpinned") and this front end
+to an output the reference itself holds.  The remaining difference is JPEG decoding (PIL here, OpenCV's libjpeg
+there) and cornerSubPix's stopping rule; it is bounded by the tolerances below.
+
+cv.findChessboardCorners' own detector cannot be restated without its source (it is not in the reference): the
+candidate detector is this repository's (integer ChESS response) with a CPU twin in oracle/chessboard.cpp."""
+import os
+
+import numpy as np
+import pytest
+from PIL import Image
+
+from cameracalibration_amd.camera_sync import chessboard as cb
+from tests import _data, _oracle as orc
+
+N_PHOTOS = 9
+
+
+def _photo(i):
+    """Decode like cv.imread: 8-bit BGR."""
+    rgb = np.array(Image.open(os.path.join(_data.GOLDEN, "calib", "frame%d.jpg" % i)).convert("RGB"))
+    return np.ascontiguousarray(rgb[:, :, ::-1])
+
+
+def _objp():
+    objp = np.zeros((49, 3), np.float32)
+    objp[:, :2] = np.mgrid[0:7, 0:7].T.reshape(-1, 2)  # camera.py:38-41
+    return objp
+
+
+def _oracle_corners(bgr):
+    gray = orc.bgr2gray(bgr)
+    xy, _ = orc.chess_candidates(gray, 1)
+    G = cb.grow_lattice(xy[:49], (7, 7))
+    assert G is not None
+    start = cb.canonical_order(G).reshape(-1, 2).astype(np.float32)
+    return start, orc.corner_subpix(gray, start, 11, 30, 0.001)
+
+
+def _close_to_reference_calibration(mtx, dist):
+    ref_K, ref_d = _data.calibration("robot_640-480_500.npz")
+    assert abs(mtx[0, 0] - ref_K[0, 0]) < 0.05 and abs(mtx[1, 1] - ref_K[1, 1]) < 0.05, (mtx, ref_K)
+    assert abs(mtx[0, 2] - ref_K[0, 2]) < 0.02 and abs(mtx[1, 2] - ref_K[1, 2]) < 0.02, (mtx, ref_K)
+    assert np.abs(np.asarray(dist).ravel() - ref_d.ravel()).max() < 5e-4, (dist, ref_d)
+    # and it is not any of the other stored calibrations
+    other_K, _ = _data.calibration("Logitec_A_640-480_10.npz")
+    assert abs(mtx[0, 0] - other_K[0, 0]) > 10
+
+
+def test_p5_reference_photos_reproduce_the_stored_calibration():
+    """Oracle chain on the CPU: the pin itself."""
+    obj, img = [], []
+    for i in range(1, N_PHOTOS + 1):
+        start, sub = _oracle_corners(_photo(i))
+        assert np.abs(sub - start).max() < 2.0  # the candidates sit on the saddle points already
+        obj.append(_objp())
+        img.append(sub)
+    rms, K, d, _, _, _ = orc.calibrate(np.array(obj), np.array(img), (640, 480), False)
+    assert rms < 0.2
+    _close_to_reference_calibration(K, d)
+
+
+def test_candidates_of_the_photos_are_the_49_inner_corners():
+    for i in (1, 9):
+        xy, st = orc.chess_candidates(orc.bgr2gray(_photo(i)), 1)
+        assert len(xy) >= 49 and st[48] > 1.25 * st[49]  # a clear gap after the pattern's corners
+        assert np.all(np.diff(st) <= 0)
+
+
+def test_lattice_from_shuffled_perspective_points_with_impostors():
+    rng = np.random.default_rng(3)
+    H = np.array([[30.0, 6.0, 120.0], [-4.0, 27.0, 90.0], [0.00012, 0.0002, 1.0]])
+    g = np.array([[i, j, 1.0] for j in range(7) for i in range(7)])
+    p = g @ H.T
+    p = p[:, :2] / p[:, 2:]
+    pts = np.concatenate([p + rng.normal(0, 0.3, p.shape), [[20.0, 400.0], [600.0, 30.0], [330.0, 470.0]]])
+    perm = rng.permutation(len(pts))
+    G = cb.grow_lattice(pts[perm], (7, 7))
+    assert G is not None and G.shape == (7, 7, 2)
+    C = cb.canonical_order(G).reshape(-1, 2)
+    # same point set, consistent right-handed walk starting along +x
+    assert sorted(map(tuple, np.round(C, 6))) == sorted(map(tuple, np.round(pts[:49], 6)))
+    rows = C.reshape(7, 7, 2)
+    du, dv = rows[0, -1] - rows[0, 0], rows[-1, 0] - rows[0, 0]
+    assert du[0] * dv[1] - du[1] * dv[0] > 0 and du[0] > abs(du[1])
+    # every step along a row / a column keeps its direction
+    assert (np.einsum("rck,k->rc", np.diff(rows, axis=1), du) > 0).all() and (np.einsum("rck,k->rc", np.diff(rows, axis=0), dv) > 0).all()
+    assert cb.grow_lattice(pts[:40], (7, 7)) is None
+    # a mirrored lattice is put back into a right-handed order
+    M = cb.canonical_order(rows[:, ::-1])
+    du, dv = M[0, -1] - M[0, 0], M[-1, 0] - M[0, 0]
+    assert du[0] * dv[1] - du[1] * dv[0] > 0
+
+
+@pytest.mark.gpu
+def test_gpu_candidates_and_subpix_equal_the_cpu_twin():
+    from cameracalibration_amd import _hip
+    photos = np.stack([_photo(i) for i in range(1, N_PHOTOS + 1)])
+    ctx = _hip.Context(480, 640, N_PHOTOS)
+    for scale in (1, 2):
+        got = ctx.chess_candidates(photos, scale=scale)
+        for b in range(N_PHOTOS):
+            xy, st = orc.chess_candidates(orc.bgr2gray(photos[b]), scale)
+            assert np.array_equal(got[b][0], xy) and np.array_equal(got[b][1], st), (scale, b)
+    starts = np.stack([_oracle_corners(p)[0] for p in photos])
+    sub = ctx.corner_subpix(photos, starts, 11, 30, 0.001)
+    for b in range(N_PHOTOS):
+        want = orc.corner_subpix(orc.bgr2gray(photos[b]), starts[b], 11, 30, 0.001)
+        assert np.abs(sub[b] - want).max() <= 1e-3
+    # gray input, one frame, ragged point counts
+    g = orc.bgr2gray(photos[0])
+    one = ctx.corner_subpix(g, starts[:1], 11, 30, 0.001, npts=[10])
+    assert np.abs(one[0, :10] - sub[0, :10]).max() <= 1e-3 and np.array_equal(one[0, 10:], starts[0, 10:])
+
+
+@pytest.mark.gpu
+def test_camera_calibrate_on_the_reference_photos():
+    """Camera.calibrate(frames) as the reference calls it (camera.py:203-222), on the reference's own photos."""
+    from cameracalibration_amd.camera_sync.camera import Camera
+    frames = [_photo(i) for i in range(1, N_PHOTOS + 1)]
+    mtx, dist = Camera.calibrate(frames, (7, 7))
+    assert mtx.shape == (3, 3) and dist.shape == (1, 5)
+    _close_to_reference_calibration(mtx, dist)
+    # against the oracle chain on the same pixels: the north-star tolerances
+    obj, img = [], []
+    for f in frames:
+        obj.append(_objp())
+        img.append(_oracle_corners(f)[1])
+    rms0, K0, d0, _, _, _ = orc.calibrate(np.array(obj), np.array(img), (640, 480), False)
+    assert np.allclose(mtx, K0, atol=2e-3) and np.allclose(dist.ravel(), d0, atol=1e-4)
+    # the mirror's findChessboardCorners / cornerSubPix, one image, like camera.py:52-58
+    ret, corners = cb.findChessboardCorners(frames[0], (7, 7))
+    assert ret and corners.shape == (49, 1, 2) and corners.dtype == np.float32
+    c2 = cb.cornerSubPix(frames[0], corners, (11, 11), (-1, -1), (cb.TERM_CRITERIA_EPS + cb.TERM_CRITERIA_MAX_ITER, 30, 0.001))
+    assert np.abs(c2.reshape(-1, 2) - img[0]).max() <= 1e-3
+    cam = Camera("robot", -1, focus=500, resolution=(640, 480))
+    cam.calibrateCamera(frames)
+    assert cam.calibrated and np.array_equal(cam.mtx, mtx)
+    blank = [np.full((480, 640, 3), 127, np.uint8)]
+    with pytest.raises(Exception):
+        Camera.calibrate(blank)
