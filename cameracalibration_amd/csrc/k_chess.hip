@@ -11,8 +11,8 @@
 //   MR = |mean(ring) - mean(centre cross)| * 16                 large on a blob
 //   R  = SR - DR - MR
 // followed by non-maximum suppression in a (10 s + 1)^2 window and a threshold of max(R) / 20.  The lattice is
-// assembled on the host (camera_sync/chessboard.py).  All integers: the CPU twin in oracle/chessboard.cpp gives the
-// same candidates bit for bit; the end-to-end pin is the reference's own calibration result (tests/test_chessboard.py).
+// assembled on the host (camera_sync/chessboard.py).  All integers, so the tests' CPU twin gives the same candidates
+// bit for bit; the end-to-end pin is the reference's own calibration result (tests/test_chessboard.py).
 #include "internal.h"
 
 #include <algorithm>
