@@ -244,7 +244,7 @@ class Context:
         return dict(candidates=int(out[0]), contours=int(out[1]), points=int(out[2]), markers=int(out[3]),
                     overflow=int(out[4]), quads=int(out[5]), long_candidates=int(out[6]), queue_head=int(out[7]))
 
-    LIST_NAMES = ("starts", "long_starts", "contours", "points", "store_tasks", "chain_chunks", "copy_tasks", "tail")
+    LIST_NAMES = ("starts", "long_starts", "contours", "points", "store_tasks", "segments", "copy_tasks", "seeds")
 
     def debug_lists(self):
         """{list: (entries used by the last chunk, capacity)} of the chunk-wide scratch lists."""

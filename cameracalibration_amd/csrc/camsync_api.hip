@@ -268,9 +268,14 @@ int ensure_planes(camsync_ctx* c, int nScales) {
     if (nScales <= c->planeScales) return CAMSYNC_OK;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->buf.planes) (void)hipFree(c->buf.planes);
+    if (c->buf.hashKeys) (void)hipFree(c->buf.hashKeys);
+    if (c->buf.hashVals) (void)hipFree(c->buf.hashVals);
     c->buf.planes = nullptr;
+    c->buf.hashKeys = c->buf.hashVals = nullptr;
     c->planeScales = 0;
     HIPCHK(c, dalloc(&c->buf.planes, (size_t)c->maxB * nScales * plane_words(c->maxH, (c->maxW + 31) / 32)));
+    HIPCHK(c, dalloc(&c->buf.hashKeys, (size_t)c->maxB * nScales * ((size_t)c->buf.hashMask + 1)));
+    HIPCHK(c, dalloc(&c->buf.hashVals, (size_t)c->maxB * nScales * ((size_t)c->buf.hashMask + 1)));
     c->planeScales = nScales;
     return CAMSYNC_OK;
 }
@@ -283,6 +288,7 @@ int enqueue_detect(camsync_ctx* c, const uint8_t* d_in, int B, int H, int W, int
     if (cfg.maxPerim > 2 * kCkMax * kCkStride - 4)
         return fail(c, CAMSYNC_E_ARG, "maxMarkerPerimeterRate gives contours of up to %d points, the border follower handles %d",
                     cfg.maxPerim, 2 * kCkMax * kCkStride - 4);
+    HIPCHK(c, hipMemsetAsync(c->buf.hashKeys, 0, sizeof(uint32_t) * ((size_t)c->buf.hashMask + 1) * B * cfg.nScales, c->stream));
     const bool fused = gray_thresh_is_fused(cfg);
     if (!fused) {
         rcp = ensure_gray(c);
@@ -354,8 +360,8 @@ int check_overflow(camsync_ctx* c) {
     if (h.overflow)
         return fail(c, CAMSYNC_E_CAPACITY,
                     "detection scratch overflow (mask 0x%x: 1 starts, 2 contours, 4 points, 8 quads, 32 markers, 64 store/copy tasks, "
-                    "128 bad contour record, 256 chain chunks); candidates %u contours %u points %u chain %u copies %u",
-                    h.overflow, h.nCand, h.nContours, h.nPool, h.nChain, h.nCopy);
+                    "128 bad contour record, 512 border seeds / segments); candidates %u contours %u points %u seeds %u segments %u copies %u",
+                    h.overflow, h.nCand, h.nContours, h.nPool, h.nSeeds, h.nSeeds + h.nLong + h.nVirt, h.nCopy);
     return CAMSYNC_OK;
 }
 
@@ -466,11 +472,22 @@ int camsync_create(camsync_ctx** out, int device, int max_h, int max_w, int max_
     HIPCHK(c, dalloc(&b.pool, b.poolCap));
     b.taskCap = (unsigned)std::min<size_t>((size_t)b.contourCap * 2 + b.poolCap / kCkStride + kLongWaves * 128 + (size_t)8192 * 32, 0x7FFFFFFFu);
     HIPCHK(c, dalloc(&b.tasks, b.taskCap));
-    HIPCHK(c, dalloc(&b.ckpt, (size_t)kTraceWaves * 32 * 2 * kCkMax));
-    // step directions of the borders the decide passes follow (kept or not): one 128-byte chunk per 256 steps and at
-    // least one per border and direction; copy tasks: one per piece of a kept border
-    // (measured on the 4K scene of BASELINE configs[2]: 2500 chunks per frame; budget px / 2048 = 4050)
-    b.chainCap = (unsigned)std::min<size_t>(B * std::max<size_t>(2048, px / 2048) + kLongWaves * 256, 0x03FFFFFFu);
+    // long borders in segments (internal.h, SegRec): seeds, one record and one 128-byte chain chunk per segment, the
+    // seed -> id table (twice the seed list, a power of two).  Measured on the bench scene: ~1000 seeds and ~1500
+    // records per 1080p frame; on the 4K scene of configs[2] four times that.
+    b.seedCap = (unsigned)std::min<size_t>(B * std::max<size_t>(2048, px / 512) + 65536, 0x01FFFFFFu);
+    HIPCHK(c, dalloc(&b.seeds, b.seedCap));
+    b.segCap = (unsigned)std::min<size_t>(2 * (size_t)b.seedCap, 0x03FFFFFFu);
+    HIPCHK(c, dalloc(&b.seg, b.segCap));
+    {   // one sub-table per bit plane (allocated with the planes, ensure_planes)
+        size_t hs = 1;
+        while (hs < std::max<size_t>(2048, px / 512)) hs <<= 1;
+        b.hashMask = (unsigned)(hs - 1);
+        HIPCHK(c, dalloc(&b.hashKeys, B * c->planeScales * hs));
+        HIPCHK(c, dalloc(&b.hashVals, B * c->planeScales * hs));
+    }
+    b.ckpt = nullptr;
+    b.chainCap = b.segCap;
     HIPCHK(c, dalloc(&b.chain, (size_t)b.chainCap * 32));
     b.copyCap = b.taskCap;
     HIPCHK(c, dalloc(&b.copies, b.copyCap));
@@ -510,7 +527,7 @@ void camsync_destroy(camsync_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DetBuffers& b = c->buf;
     void* ptrs[] = {c->d_chessGray, c->d_chessS, c->d_chessR, c->d_chessCand, c->d_chessMax, c->d_chessCount, c->d_spIn, c->d_spOut, c->d_spN,
-                    c->d_umap, c->d_uout, c->d_in, c->d_bin, b.planes, b.gray, b.cand, b.candLong, b.contours, b.pool, b.tasks, b.ckpt, b.chain, b.copies, b.quads, b.qcount, b.counters, b.markers,
+                    c->d_umap, c->d_uout, c->d_in, c->d_bin, b.planes, b.gray, b.cand, b.candLong, b.contours, b.pool, b.tasks, b.seeds, b.seg, b.hashKeys, b.hashVals, b.chain, b.copies, b.quads, b.qcount, b.counters, b.markers,
                     b.outIds, b.outCorners, b.rawCorners, b.outCounts, b.outRejected, b.outRejCounts, c->d_dict, c->d_expTab,
                     c->d_obj, c->d_img, c->d_npts, c->d_K, c->d_dist, c->d_rvec, c->d_tvec, c->d_mae, c->d_rmse, c->d_ok,
                     c->d_anchorIds, c->d_anchorObj, c->d_calObj, c->d_calImg, c->cal.intr, c->cal.ext, c->cal.intrTrial,
@@ -781,7 +798,7 @@ int camsync_detect_pnp_resident(camsync_ctx* c, const uint8_t* d_frames, int B, 
     if (overflowSeen)
         return fail(c, CAMSYNC_E_CAPACITY,
                     "detection scratch overflow (mask 0x%x: 1 starts, 2 contours, 4 points, 8 quads, 32 markers, 64 store/copy tasks, "
-                    "128 bad contour record, 256 chain chunks)", overflowSeen);
+                    "128 bad contour record, 512 border seeds / segments)", overflowSeen);
     return CAMSYNC_OK;
 }
 
@@ -878,9 +895,8 @@ int camsync_debug_lists(camsync_ctx* c, uint32_t used[8], uint32_t cap[8]) {
     Counters h;
     HIPCHK(c, hipMemcpy(&h, c->buf.counters, sizeof h, hipMemcpyDeviceToHost));
     const DetBuffers& b = c->buf;
-    const uint32_t u[8] = {h.nCand, h.nLong, h.nContours, h.nPool, h.nTasks, h.nChain, h.nCopy, h.nTail};
-    const uint32_t k[8] = {b.candCap, b.candCap, b.contourCap, b.poolCap, b.taskCap, b.chainCap, b.copyCap,
-                           (uint32_t)(kTraceWaves * kTailPairs)};
+    const uint32_t u[8] = {h.nCand, h.nLong, h.nContours, h.nPool, h.nTasks, h.nSeeds + h.nLong + h.nVirt, h.nCopy, h.nSeeds};
+    const uint32_t k[8] = {b.candCap, b.candCap, b.contourCap, b.poolCap, b.taskCap, b.segCap, b.copyCap, b.seedCap};
     for (int i = 0; i < 8; i++) { used[i] = u[i]; cap[i] = k[i]; }
     return CAMSYNC_OK;
 }

@@ -97,6 +97,30 @@ struct CopyTask {
     uint32_t dst;    // pool index of that pixel
     uint32_t n;      // points; bit 31: the following points go to dst - 1, dst - 2, ...
 };
+// Long borders are followed in segments.  A *seed* is a place on a border that can be recognised from the 3x3
+// neighbourhood alone and where a follower can start without knowing where the border began: a foreground pixel on a
+// row y = 0 (mod 32) whose west neighbour is background (the follower starts as if it had just swept that crack), on
+// a row y = 16 (mod 32) whose east neighbour is background, or, on the other rows, on a column x = 0 / 16 (mod 32)
+// whose north / south neighbour is background; in all cases only where the border goes on on both sides of the crack
+// (foreground in the three pixels above and below, or left and right), which keeps noise specks out.  A pixel can
+// carry one seed at most, so (plane, pixel) names it.  Every seed's follower walks until its sweep passes the crack of the next seed: that is one
+// segment (at most kSegLen points; a longer stretch is cut by continuation segments).  The segments of a border form a
+// ring through their `next` links, so a border of any length costs kSegLen dependent steps instead of its length.
+struct SegRec {
+    uint32_t next;     // segment that continues the border, or one of the kSeg* marks
+    uint32_t len;      // points of this segment
+    uint32_t minAll;   // smallest raster key y * W + x among its points
+    uint32_t minEast;  // the same among the points whose east crack lies on the border (hole borders start there)
+    uint32_t chunk;    // chain chunk holding the direction of every step
+    uint32_t start;    // x | y << 16 of its first point
+    uint32_t pad0, pad1;
+};
+constexpr uint32_t kSegSelf = 0xFFFFFFFFu;   // (start candidates only) the border closed on the candidate's own start state
+constexpr uint32_t kSegAbort = 0xFFFFFFFEu;  // (start candidates only) not the canonical start, or longer than allowed
+constexpr uint32_t kSegNone = 0xFFFFFFFDu;   // no record: a list overflowed
+constexpr uint32_t kSegPending = 0xFFFFFFFCu;  // ends at a seed whose id k_seg_link still has to look up (pad0 / pad1 say which)
+constexpr int kSegLen = 256;                  // = kCkStride: one chain chunk per segment
+
 constexpr int kTraceWaves = 256 * 16;  // persistent single-wave workgroups of the long-border kernels
 constexpr int kCkStride = 256;         // a checkpoint (and a store task) every this many points
 constexpr int kTailPairs = 16;          // a decide wave with at most this many borders left hands them to the tail pass
@@ -120,7 +144,7 @@ struct Counters {
     unsigned int nContours;
     unsigned int nPool;
     unsigned int nMarkers;
-    unsigned int overflow;  // 1 starts, 2 contours, 4 points, 8 quads, 32 markers, 64 store/copy tasks, 128 bad contour record, 256 chain chunks
+    unsigned int overflow;  // 1 starts, 2 contours, 4 points, 8 quads, 32 markers, 64 store/copy tasks, 128 bad contour record, 512 border seeds / segments
     unsigned int nLong;     // candidates handed from the short-trace pass to the long-trace pass
     unsigned int qDecide;   // work-queue heads of the long-border kernels (lanes fetch their next border here)
     unsigned int qStore;
@@ -129,6 +153,10 @@ struct Counters {
     unsigned int nTail;     // border pairs handed from the decide pass to its tail pass
     unsigned int nChain;    // chain chunks handed out
     unsigned int nCopy;     // copy tasks appended by the decide passes
+    unsigned int nSeeds;    // border seeds found by the start pass (see SegRec)
+    unsigned int nVirt;     // continuation segments handed out by the segment walkers (ids count down from segCap - 1)
+    unsigned int qWalk;     // work-queue heads of the segment walkers and of the resolve pass
+    unsigned int qResolve;
     unsigned int pad;
 };
 
@@ -182,6 +210,13 @@ struct DetBuffers {
     unsigned int chainCap;
     CopyTask* copies;
     unsigned int copyCap;
+    uint64_t* seeds;     // border seeds, packed like start candidates (bit 39: 0 = west crack, 1 = north crack)
+    unsigned int seedCap;
+    SegRec* seg;         // [segCap] ids: [0, nSeeds) seeds, [nSeeds, nSeeds + nLong) start candidates, continuations from the top down
+    unsigned int segCap;
+    uint32_t* hashKeys;  // seed -> id: one open-addressing sub-table of hashMask + 1 slots per bit plane (position + 1, 0 = empty)
+    uint32_t* hashVals;
+    unsigned int hashMask;
     QuadRec* quads;      // [B,kQuadCap]
     int* qcount;         // [B]
     Counters* counters;

@@ -54,6 +54,7 @@ __device__ __forceinline__ uint32_t fill_down(uint32_t seed, uint32_t run) {
 }
 
 constexpr int kStage = 512;  // starts staged per wavefront before a flush
+constexpr int kSeedStage = 256;  // border seeds likewise
 
 // word (xw, y) of a block-linear plane, zero outside the plane
 __device__ __forceinline__ uint32_t pw_at(const uint32_t* __restrict__ plane, int WS, int H, int xw, int y) {
@@ -67,12 +68,24 @@ __device__ __forceinline__ uint32_t pw_at(const uint32_t* __restrict__ plane, in
 // the one bit that crosses a word boundary comes from the neighbouring lane (DPP wave shifts): about twenty vector
 // instructions per 32 pixels when nothing starts in them.  Two groups of rows are loaded ahead of the one being
 // processed.  Starts are staged in LDS and appended to the global list with one atomic per flush.
+// Seed grid pitch G (a power of two, >= 32): the pixels of word bx (32 pixels) that lie on a north-seed column
+// (x = 0 mod G, where `north` must hold) or a south-seed column (x = G/2 mod G, where `south` must hold).
+constexpr int kSeedGrid = 64;
+__device__ __forceinline__ uint32_t seed_columns(int bx, uint32_t north, uint32_t south) {
+    if (kSeedGrid == 32) return (north & 1u) | (south & 0x10000u);
+    const int wm = bx & (kSeedGrid / 32 - 1);
+    return wm == 0 ? (north & 1u) : wm == kSeedGrid / 64 ? (south & 1u) : 0u;
+}
+
 constexpr int kStartCols = 62;  // useful block columns per wavefront (lanes 1..62)
 
 __global__ __launch_bounds__(64) void k_contour_starts(const uint32_t* __restrict__ planes, DetCfg cfg, int B, int bands,
                                                        int bandGroups, uint64_t* __restrict__ cand, unsigned int candCap,
+                                                       uint64_t* __restrict__ seeds, unsigned int seedCap,
                                                        Counters* __restrict__ ctr) {
     __shared__ uint64_t stage[kStage];
+    __shared__ uint64_t seedStage[kSeedStage];
+    unsigned int seedStaged = 0;  // uniform
     const int H = cfg.H, WS = cfg.WS, S = cfg.nScales, W = cfg.W, HB = plane_hb(H);
     const int colGroups = (WS + kStartCols - 1) / kStartCols;
     const size_t perPlane = plane_words(H, WS);
@@ -91,6 +104,18 @@ __global__ __launch_bounds__(64) void k_contour_starts(const uint32_t* __restric
             const unsigned int fit = g >= candCap ? 0u : min(staged, candCap - g);
             for (unsigned int k = lane; k < fit; k += 64) cand[g + k] = stage[k];
             staged = 0;
+        }
+    };
+
+    auto flush_seeds = [&]() {
+        if (seedStaged) {
+            unsigned int g = 0;
+            if (lane == 0) g = atomicAdd(&ctr->nSeeds, seedStaged);
+            g = __builtin_amdgcn_readfirstlane(g);
+            if (g + seedStaged > seedCap && lane == 0) atomicOr(&ctr->overflow, 512u);
+            const unsigned int fit = g >= seedCap ? 0u : min(seedStaged, seedCap - g);
+            for (unsigned int k = lane; k < fit; k += 64) seeds[g + k] = seedStage[k];
+            seedStaged = 0;
         }
     };
 
@@ -219,6 +244,31 @@ __global__ __launch_bounds__(64) void k_contour_starts(const uint32_t* __restric
                     staged += layer;
                 }
             }
+            // ---- border seeds (internal.h, SegRec): west / east cracks on rows y = 0 / G/2 (mod G), north / south cracks
+            //      on columns x = 0 / G/2 (mod G) of the other rows (G = kSeedGrid); a pixel carries at most one seed ----
+            {
+                const int ym = y & (kSeedGrid - 1);  // uniform
+                uint32_t sm;
+                if (ym == 0) sm = c & ~cw & (pc | pw | pe) & (sd | sw | se);
+                else if (ym == kSeedGrid / 2) sm = c & ~ce & (pc | pw | pe) & (sd | sw | se);
+                else sm = c & (pw | cw | sw) & (pe | ce | se) & seed_columns(bx, ~pc, ~sd);
+                sm &= om;
+                if (__any(sm != 0)) {
+                    const uint32_t rowPos = (uint32_t)y * W + 32u * bx;
+                    for (;;) {
+                        const unsigned long long bal = __ballot(sm != 0);
+                        if (!bal) break;
+                        const unsigned int layer = (unsigned int)__popcll(bal);
+                        if (seedStaged + layer > (unsigned int)kSeedStage) flush_seeds();
+                        if (sm) {
+                            seedStage[seedStaged + (unsigned int)__popcll(bal & ((1ull << lane) - 1ull))] =
+                                pack_cand(f, 0u, sc, rowPos + (__ffs(sm) - 1));
+                            sm &= sm - 1;
+                        }
+                        seedStaged += layer;
+                    }
+                }
+            }
             pc = c; pw = cw; pe = ce;
             cw = sw; ce = se;
         }
@@ -227,6 +277,7 @@ __global__ __launch_bounds__(64) void k_contour_starts(const uint32_t* __restric
         nx2 = nx3;
     }
     flush();
+    flush_seeds();
 }
 
 // 3-bit fields (x-1, x, x+1) of rows y-1, y, y+1 -> neighbour mask, bit d = neighbour in direction d.
@@ -428,8 +479,7 @@ __device__ __forceinline__ uint32_t from_partner(uint32_t v) {
 // A wave takes work from a global queue in batches and hands the items to its idle lanes, and it reserves
 // output space (points, contour records, store tasks) in blocks that it sub-allocates itself: the global
 // counters are touched once per block instead of once per border (they are single hot addresses).
-constexpr unsigned int kPoolBlock = 16384, kSlotBlock = 8, kTaskBlock = 128, kDecideBatch = 64, kStoreBatch = 256;
-constexpr unsigned int kChainBlock = 256;  // chain chunks a wave takes from the global counter at a time
+constexpr unsigned int kPoolBlock = 16384, kSlotBlock = 8, kTaskBlock = 128, kStoreBatch = 256;
 
 struct WaveQueue {
     unsigned int lo = 0, hi = 0;
@@ -686,279 +736,396 @@ __global__ __launch_bounds__(256) void k_trace_short(const uint32_t* __restrict_
     mark_empty_tasks(tasks, taskA.cur, taskA.end, lane);
 }
 
-// A border in flight, as one lane of its pair holds it (the tail pass resumes from these).
-struct TailRec {
-    uint64_t c;
-    uint32_t count, pos, prevState, state0, ck, chunk, acc, fail;
-};
-static_assert(sizeof(TailRec) == 40, "tail records are sized against the start list (camsync_create)");
+// ---- long borders in segments (internal.h, SegRec) ------------------------------------------------------
+// seed -> id table.  Every bit plane has its own open-addressing sub-table of (subMask + 1) slots, so that the inserts
+// and lookups of a plane stay within a few tens of kilobytes (the seeds of a plane are listed, and its borders followed,
+// close together in time); key = pixel position + 1, 0 = empty.
+__device__ __forceinline__ uint32_t seed_hash(uint32_t pos) {
+    uint32_t h = pos * 0x9E3779B1u;
+    return h ^ (h >> 15);
+}
 
-// Decide the long candidates (canonical start? length within bounds?), reserve pool space and cut the accepted
-// borders into store tasks.  Lanes 2p (forward) and 2p + 1 (backward) work on the same candidate.
-//
-// The lengths are heavy-tailed: once the queue is empty most waves would spend two thirds of their life
-// following one or two very long borders with 60 idle lanes, all of them competing for issue slots.  A wave
-// whose queue is empty and that has at most kTailPairs borders left therefore writes their state to the tail
-// list and exits; the RESUME instance packs those borders 32 to a wave and finishes them.
-constexpr int kTailLanes = 64;  // lanes (two per border) a wave of the tail pass takes over (fewer per wave was slower)
-template <bool RESUME>
-__global__ __launch_bounds__(64) void k_trace_decide(const uint32_t* __restrict__ planes, DetCfg cfg,
-                                                     const uint64_t* __restrict__ candLong, unsigned int candCap,
-                                                     TailRec* __restrict__ tail,
-                                                     ContourRec* __restrict__ contours, unsigned int contourCap,
-                                                     unsigned int poolCap, CopyTask* __restrict__ tasks, unsigned int taskCap,
-                                                     uint2* __restrict__ ckpt, uint32_t* __restrict__ chain, unsigned int chainCap,
-                                                     Counters* __restrict__ ctr) {
+// one lane per seed
+__global__ __launch_bounds__(256) void k_seed_hash(const uint64_t* __restrict__ seeds, unsigned int seedCap, int S,
+                                                   uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                                                   unsigned int subMask, Counters* __restrict__ ctr) {
+    const unsigned int n = min(ctr->nSeeds, seedCap);
+    for (unsigned int i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const uint64_t c = seeds[i];
+        const uint32_t key = (uint32_t)(c & 0xFFFFFFFFull) + 1u;
+        const size_t base = ((size_t)(uint32_t)(c >> 40) * S + (uint32_t)((c >> 36) & 7u)) * ((size_t)subMask + 1);
+        unsigned int slot = seed_hash(key) & subMask;
+        bool placed = false;
+        for (unsigned int probe = 0; probe <= subMask; probe++) {
+            const uint32_t prev = atomicCAS(&keys[base + slot], 0u, key);
+            if (prev == 0u || prev == key) {
+                vals[base + slot] = i;
+                placed = true;
+                break;
+            }
+            slot = (slot + 1) & subMask;
+        }
+        if (!placed) atomicOr(&ctr->overflow, 512u);  // more seeds in one plane than its sub-table holds
+    }
+}
+
+__device__ __forceinline__ uint32_t seed_lookup(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                                unsigned int subMask, size_t planeId, uint32_t pos) {
+    const uint32_t key = pos + 1u;
+    const size_t base = planeId * ((size_t)subMask + 1);
+    unsigned int slot = seed_hash(key) & subMask;
+    for (unsigned int probe = 0; probe <= subMask; probe++) {
+        const uint32_t k = keys[base + slot];
+        if (k == key) return vals[base + slot];
+        if (k == 0u) break;
+        slot = (slot + 1) & subMask;
+    }
+    return kSegNone;
+}
+
+// Which crack of pixel (x, y) can be a seed: direction of the background neighbour (4 west, 0 east, 2 north, 6 south).
+// Rows 0 / G/2 (mod G) carry west / east seeds, the other rows north / south seeds at columns 0 / G/2 (mod G);
+// -1: the pixel cannot be a seed.  The start pass applies the same rule word-wide (seed_columns).
+__device__ __forceinline__ int seed_dir(int x, int y) {
+    const int ym = y & (kSeedGrid - 1), xm = x & (kSeedGrid - 1);
+    return ym == 0 ? 4 : ym == kSeedGrid / 2 ? 0 : xm == 0 ? 2 : xm == kSeedGrid / 2 ? 6 : -1;
+}
+// ... and the border must go on on both sides of the crack (m = neighbour mask, bit d = direction d)
+__device__ __forceinline__ bool seed_supported(uint32_t m, int dir) {
+    return (dir & 2) ? ((m & 0x38u) && (m & 0x83u))   // north / south crack: something to the left and to the right
+                     : ((m & 0x0Eu) && (m & 0xE0u));  // west / east crack: something above and below
+}
+
+// One lane per work item: items [0, nSeeds) are seeds, [nSeeds, nSeeds + nLong) the start candidates the short pass
+// left undecided.  A lane follows its border forwards (successor map T, inside its private LDS window) and records
+// the direction of every step, until its sweep passes the crack of a seed: the segment ends there and the record
+// keeps that seed's key (k_seg_link turns it into an id afterwards: a table lookup here would stall the whole wave at
+// almost every step).  After kSegLen points without a seed the lane closes the segment with a continuation record
+// and goes on in it.  A start candidate also stops when it is back at its own start state (a border without seeds)
+// and gives up as soon as it meets a crack with a smaller raster key (it is not the canonical start) or exceeds the
+// length bound.  Lanes hold their next work item in registers, so that taking it up does not wait for memory.
+__global__ __launch_bounds__(64) void k_seg_walk(const uint32_t* __restrict__ planes, DetCfg cfg,
+                                                 const uint64_t* __restrict__ seeds, unsigned int seedCap,
+                                                 const uint64_t* __restrict__ candLong, unsigned int candCap,
+                                                 SegRec* __restrict__ seg, unsigned int segCap,
+                                                 uint32_t* __restrict__ chain, Counters* __restrict__ ctr) {
     __shared__ __align__(8) uint32_t tile[kTileWords];
     const int lane = threadIdx.x;
-    const bool bw = lane & 1;
-    const unsigned int n = RESUME ? 0u : min(ctr->nLong, candCap);
+    const unsigned int nSeeds = min(ctr->nSeeds, seedCap), nLong = min(ctr->nLong, candCap);
+    const unsigned int nItems = min(nSeeds + nLong, segCap);
     const int H = cfg.H, W = cfg.W, WS = cfg.WS, S = cfg.nScales;
     const size_t perPlane = plane_words(H, WS);
-    uint32_t ckSlot = ((uint32_t)blockIdx.x * 32 + (lane >> 1)) * 2 + (bw ? 1 : 0);
-    uint2* myCk = ckpt + (size_t)ckSlot * kCkMax;
-    // the directions of this lane's steps, eight to a word, go to chunks of kCkStride steps (see CopyTask)
-    uint32_t chAcc = 0, chChunk = ~0u;
-    uint32_t* chWords = chain;  // the current chunk's 32 words
-    bool chFail = false;
 
-    bool active = false, exhausted = false, fresh = false, isHole = false;
-    uint64_t c = 0;
-    int count = 0, startKey = 0, cx = 1, cy = 1, s = 0;
-    uint32_t prevState = 0, state0 = 0;  // last completed state of this lane; the start state
+    // walking: following a border; ended: a segment is complete and waits for the service phase to write its record
+    bool walking = false, ended = false, goesOn = false, fresh = false, isCand = false, isHole = false;
+    uint64_t c = 0, nextC = 0;
+    uint32_t nextI = ~0u;   // the item this lane takes up next (~0u: none fetched)
+    bool exhausted = false;  // the queue has nothing more for this lane
+    uint32_t id = 0, count = 0, total = 0, minAll = 0xFFFFFFFFu, minEast = 0xFFFFFFFFu, startPix = 0, state0 = 0, chAcc = 0;
+    uint32_t endNext = kSegNone, endKey = 0;
+    int startKey = 0, cx = 1, cy = 1, s = 0;
     const uint32_t* plane = planes;
     TileWin win;
     win.gx = win.gy = 0;
     win.valid = false;
     WaveQueue queue;
-    WaveAlloc poolA, slotA, taskA, chainA;
 
-    if (RESUME) {
-        // one record per lane, pairs adjacent; nothing else to fetch
-        const unsigned int nRec = 2u * min(ctr->nTail, (unsigned int)(kTraceWaves * kTailPairs));
-        const unsigned int i = blockIdx.x * (unsigned int)kTailLanes + (unsigned int)lane;
-        if (lane < kTailLanes && i < nRec) {
-            const TailRec r = tail[i];
-            c = r.c;
-            const uint32_t pos = (uint32_t)(c & 0xFFFFFFFFull);
-            plane = planes + ((size_t)(uint32_t)(c >> 40) * S + (int)((c >> 36) & 7u)) * perPlane;
-            isHole = (c >> 39) & 1u;
-            startKey = (int)pos;
-            count = (int)r.count;
-            cx = (int)(r.pos & 0xFFFu);
-            cy = (int)((r.pos >> 12) & 0xFFFu);
-            s = (int)(r.pos >> 24);
-            prevState = r.prevState;
-            state0 = r.state0;
-            ckSlot = r.ck;
-            myCk = ckpt + (size_t)ckSlot * kCkMax;
-            chChunk = r.chunk;
-            chWords = chain + (size_t)(chChunk == ~0u ? 0u : chChunk) * 32;
-            chAcc = r.acc;
-            chFail = r.fail != 0;
-            active = true;
+    // Everything that touches global memory or is rare -- writing a finished segment's record, taking up the next
+    // work item, moving a lane's window -- happens in a service phase every kService steps, for all lanes that need
+    // it at once: between two phases the wave runs kService lean steps (LDS and registers only).  A window is moved
+    // when its lane is within kService + 1 pixels of leaving it, so no lane can run out of window between phases.
+    constexpr int kService = kPieceRows / 2 - 2 > 1 ? kPieceRows / 2 - 2 : 1;
+    for (unsigned int iter = 0;; iter++) {
+        if (iter % kService == 0) {
+            // ---- finished segments: record, continuation ----
+            if (ended) {
+                uint32_t cont = 0, next = endNext;
+                if (goesOn) {
+                    const unsigned int v = atomicAdd(&ctr->nVirt, 1u);
+                    // continuation ids count down from the top of the record list, work items up from its bottom
+                    if (v >= segCap - nItems) {
+                        atomicOr(&ctr->overflow, 512u);
+                        next = kSegNone;
+                        goesOn = false;
+                    } else {
+                        cont = segCap - 1u - v;
+                        next = cont;
+                    }
+                }
+                if ((count & 7) != 0) chain[(size_t)id * 32 + (((count - 1) >> 3) & 31)] = chAcc;
+                SegRec r;
+                r.next = next; r.len = count; r.minAll = minAll; r.minEast = minEast; r.chunk = id; r.start = startPix;
+                // where the border goes on, for k_seg_link: position and plane of the seed reached
+                r.pad0 = endKey;
+                r.pad1 = (uint32_t)(c >> 36);  // frame << 4 | hole << 3 | scale
+                seg[id] = r;
+                ended = false;
+                if (goesOn) {
+                    id = cont;
+                    count = 0;
+                    minAll = minEast = 0xFFFFFFFFu;
+                    startPix = (uint32_t)cx | ((uint32_t)cy << 16);
+                    chAcc = 0;
+                    walking = true;
+                    goesOn = false;
+                }
+            }
+            // ---- lanes without a next item draw one (its load is in flight while the current item is followed) ----
+            {
+                const bool need = nextI == ~0u && !exhausted;
+                const unsigned int i = queue.pop<1>(need, &ctr->qWalk, nItems, 64u, lane);
+                if (need) {
+                    if (i != ~0u) {
+                        nextI = i;
+                        nextC = i >= nSeeds ? candLong[i - nSeeds] : seeds[i];
+                    } else if (queue.empty()) {
+                        exhausted = true;
+                    }
+                }
+            }
+            // ---- idle lanes take up their next item ----
+            if (!walking && nextI != ~0u) {
+                c = nextC;
+                id = nextI;
+                nextI = ~0u;
+                isCand = id >= nSeeds;
+                const uint32_t pos = (uint32_t)(c & 0xFFFFFFFFull);
+                plane = planes + ((size_t)(uint32_t)(c >> 40) * S + (int)((c >> 36) & 7u)) * perPlane;
+                cx = (int)(pos % W);
+                cy = (int)(pos / W);
+                isHole = isCand && ((c >> 39) & 1u);
+                startKey = cy * W + cx;
+                minAll = minEast = 0xFFFFFFFFu;
+                if (!isCand) {
+                    const int d = seed_dir(cx, cy);
+                    s = d < 0 ? 4 : d;                   // as if that crack had just been swept
+                    if (d == 0) minEast = (uint32_t)startKey;  // an east seed: the crack itself is an east crack of the border
+                }
+                count = 0;
+                total = 0;
+                startPix = (uint32_t)cx | ((uint32_t)cy << 16);
+                chAcc = 0;
+                win.valid = false;
+                walking = true;
+                fresh = isCand;
+            }
+            if (!__any(walking)) {
+                if (__all(exhausted && nextI == ~0u)) break;
+                continue;
+            }
+            // ---- windows ----
+            if (__any(walking && win.near_edge(cx, cy))) {
+                if (walking && win.near_edge(cx, cy)) win.recentre(plane, WS, H, cx, cy, tile, lane);
+            }
         }
-        exhausted = true;
+        if (walking && win.covers(cx, cy)) {  // (always covered, see above; a lane that is not waits for the next phase)
+            const uint32_t m = win.mask(tile, lane, cx, cy);
+            if (fresh) {  // a start candidate takes its start state (P0, s0)
+                const int s0 = fresh_dir(m, isHole);  // never -1: single pixels end in the short pass
+                s = s0 < 0 ? 0 : s0;
+                state0 = pack_state(cx, cy, s);
+                fresh = false;
+            }
+            // sweep counter-clockwise from s + 1 to the first foreground neighbour q; j background pixels are passed
+            const int b0 = (s + 1) & 7;
+            const uint32_t rot = ((m >> b0) | (m << (8 - b0))) & 0xFFu;
+            const int j = __builtin_ctz(rot | 0x100u);
+            const int q = (s + 1 + j) & 7;
+            // position of direction `dir` in the sweep: passed when 1 <= t <= j
+            const int sd = seed_dir(cx, cy);
+            const int tSeed = (sd - s) & 7, tEast = (0 - s) & 7;
+            const bool east = (unsigned int)(tEast - 1) < (unsigned int)j;
+            const bool atSeed = sd >= 0 && (unsigned int)(tSeed - 1) < (unsigned int)j && seed_supported(m, sd);
+            const uint32_t key = (uint32_t)(cy * W + cx);
+            if (atSeed) {
+                // the seed's own segment accounts for this pixel, but it starts its sweep behind the crack: an east
+                // crack passed before the seed's crack in this same sweep is accounted for here
+                if (east && tEast < tSeed) minEast = min(minEast, key);
+                endNext = kSegPending;
+                endKey = key;
+                ended = true;
+                walking = false;
+            } else if (isCand && (!isHole || east) && (int)key < startKey) {  // not the canonical start
+                endNext = kSegAbort;
+                ended = true;
+                walking = false;
+            } else {
+                minAll = min(minAll, key);
+                if (east) minEast = min(minEast, key);
+                chAcc |= (uint32_t)q << (4 * (count & 7));
+                if ((count & 7) == 7) {
+                    chain[(size_t)id * 32 + ((count >> 3) & 31)] = chAcc;
+                    chAcc = 0;
+                }
+                count++;
+                total++;
+                cx += fast_dx(q);
+                cy += fast_dy(q);
+                s = q ^ 4;
+                if (isCand && pack_state(cx, cy, s) == state0) {  // a border without seeds closed
+                    endNext = kSegSelf;
+                    ended = true;
+                    walking = false;
+                } else if (isCand && total > (uint32_t)cfg.maxPerim) {
+                    endNext = kSegAbort;
+                    ended = true;
+                    walking = false;
+                } else if (count == (uint32_t)kSegLen) {  // goes on in a continuation segment
+                    ended = true;
+                    goesOn = true;
+                    walking = false;
+                }
+            }
+        }
     }
+}
+
+// Turn "goes on at the seed at (plane, position)" into that seed's id: one lane per record.
+__global__ __launch_bounds__(256) void k_seg_link(SegRec* __restrict__ seg, unsigned int segCap, unsigned int seedCap,
+                                                  unsigned int candCap, int S, const uint32_t* __restrict__ hashKeys,
+                                                  const uint32_t* __restrict__ hashVals, unsigned int hashMask,
+                                                  Counters* __restrict__ ctr) {
+    const unsigned int nSeeds = min(ctr->nSeeds, seedCap), nLong = min(ctr->nLong, candCap);
+    const unsigned int nItems = min(nSeeds + nLong, segCap);
+    const unsigned int nVirt = min(ctr->nVirt, segCap - nItems);
+    for (unsigned int t = blockIdx.x * 256u + threadIdx.x; t < nItems + nVirt; t += gridDim.x * 256u) {
+        const unsigned int id = t < nItems ? t : segCap - 1u - (t - nItems);
+        if (seg[id].next != kSegPending) continue;
+        const uint32_t pos = seg[id].pad0, fs = seg[id].pad1;
+        const uint32_t v = seed_lookup(hashKeys, hashVals, hashMask, (size_t)(fs >> 4) * S + (fs & 7u), pos);
+        if (v == kSegNone) atomicOr(&ctr->overflow, 512u);  // (a seed the start pass could not list)
+        seg[id].next = v;
+    }
+}
+
+// Decide every undecided start candidate from the segment records and cut the accepted borders into copy tasks.
+// A candidate's own records lead to the first seed of its border (or close on themselves); from there the seeds'
+// records run once round the border.  The border is kept when no crack on it has a smaller raster key than the
+// candidate (it is the canonical start) and its length is within the perimeter bounds; its points are then the
+// candidate's own stretch followed by the ring from that first seed, cut off at the border's length.
+__global__ __launch_bounds__(64) void k_resolve(DetCfg cfg, const uint64_t* __restrict__ candLong, unsigned int candCap,
+                                                unsigned int seedCap, const SegRec* __restrict__ seg, unsigned int segCap,
+                                                ContourRec* __restrict__ contours, unsigned int contourCap, unsigned int poolCap,
+                                                CopyTask* __restrict__ tasks, unsigned int taskCap, Counters* __restrict__ ctr) {
+    const int lane = threadIdx.x;
+    const unsigned int nSeeds = min(ctr->nSeeds, seedCap), nLong = min(ctr->nLong, candCap);
+    const unsigned int nItems = min(nSeeds + nLong, segCap);
+    const unsigned int nCand = nItems > nSeeds ? nItems - nSeeds : 0u;
+    const unsigned int virtLo = segCap - min(ctr->nVirt, segCap - nItems);  // continuation ids are >= virtLo
+    const unsigned int hopCap = (unsigned int)cfg.maxPerim + 4u * (unsigned int)kSegLen;  // no ring is longer (in segments) than this
+    WaveQueue queue;
+    WaveAlloc poolA, slotA, taskA;
+    bool exhausted = false;
+
+    auto valid_id = [&](uint32_t v) { return v < nItems || (v >= virtLo && v < segCap); };
 
     for (;;) {
-        // ---- a wave left with a few borders and an empty queue hands them to the tail pass ----
-        if (!RESUME && queue.empty()) {
-            const unsigned long long am = __ballot(active);
-            const int np = __popcll(am) >> 1;
-            if (np > 0 && np <= kTailPairs) {
-                unsigned int base = 0;
-                if (lane == 0) base = atomicAdd(&ctr->nTail, (unsigned int)np);
-                base = __builtin_amdgcn_readfirstlane(base);
-                if (active) {
-                    TailRec r;
-                    r.c = c;
-                    r.count = (uint32_t)count;
-                    r.pos = pack_state(cx, cy, s);
-                    r.prevState = prevState;
-                    r.state0 = state0;
-                    r.ck = ckSlot;
-                    r.chunk = chChunk;
-                    r.acc = chAcc;
-                    r.fail = chFail ? 1u : 0u;
-                    tail[2u * base + (unsigned int)__popcll(am & ((1ull << lane) - 1ull))] = r;
-                }
-                break;
-            }
-        }
-        // ---- idle pairs fetch their next candidate (the queue hands out every index below n exactly once) ----
-        {
-            const bool need = !active && !exhausted;
-            const unsigned int i = queue.pop<2>(need, &ctr->qDecide, n, kDecideBatch, lane);
-            if (need) {
-                if (i != ~0u) {
-                    c = candLong[i];
-                    const uint32_t pos = (uint32_t)(c & 0xFFFFFFFFull);
-                    plane = planes + ((size_t)(uint32_t)(c >> 40) * S + (int)((c >> 36) & 7u)) * perPlane;
-                    cx = (int)(pos % W);
-                    cy = (int)(pos / W);
-                    isHole = (c >> 39) & 1u;
-                    startKey = cy * W + cx;
-                    count = 0;
-                    win.valid = false;
-                    active = true;
-                    fresh = true;
-                } else if (queue.empty()) {
-                    exhausted = true;
-                }
-            }
-        }
-        if (!__any(active)) {
-            if (__all(exhausted)) break;
-            continue;  // e.g. every lane drew an empty task: draw again
-        }
+        const unsigned int i = queue.pop<1>(!exhausted, &ctr->qResolve, nCand, 64u, lane);
+        const bool have = !exhausted && i != ~0u;
+        if (!exhausted && i == ~0u && queue.empty()) exhausted = true;
+        if (__all(exhausted)) break;
 
-        // ---- keep every active lane's window around its pixel ----
-        if (__any(active && !win.covers(cx, cy))) {
-            if (active && win.near_edge(cx, cy)) win.recentre(plane, WS, H, cx, cy, tile, lane);
-        }
-
-        // ---- new pairs take their start state (P0, s0); the backward lane first steps to P0 + s0 (uniform branch:
-        //      rare, and the step below follows in the same round) ----
-        if (__any(active && fresh)) {
-            if (active && fresh) {
-                const uint32_t m = win.mask(tile, lane, cx, cy);
-                fresh = false;
-                const int s0 = fresh_dir(m, isHole);  // never -1 here: single pixels end in the short pass
-                s = s0 < 0 ? 0 : s0;
-                state0 = prevState = pack_state(cx, cy, s);
-                if (bw) {  // (the window keeps a margin after a move, one pixel further is still covered)
-                    cx += fast_dx(s);
-                    cy += fast_dy(s);
-                    s ^= 4;  // now: direction towards the pixel we came from, the forward successor
+        // ---- pass 1: length of the border, smallest keys, number of records to copy from ----
+        uint32_t len = 0, nrec = 0, firstSeed = kSegNone;
+        uint64_t c = 0;
+        bool ok = false, isHole = false;
+        if (have) {
+            c = candLong[i];
+            isHole = (c >> 39) & 1u;
+            const uint32_t startKey = (uint32_t)(c & 0xFFFFFFFFull);
+            uint32_t minAll = 0xFFFFFFFFu, minEast = 0xFFFFFFFFu, own = 0;
+            uint32_t id = nSeeds + i;
+            ok = true;
+            bool closed = false;
+            // the candidate's own records
+            for (unsigned int hop = 0;; hop++) {
+                const SegRec r = seg[id];
+                if (r.next == kSegAbort || r.next == kSegNone || r.len > (uint32_t)kSegLen || hop > hopCap) { ok = false; break; }
+                own += r.len;
+                nrec++;
+                minAll = min(minAll, r.minAll);
+                minEast = min(minEast, r.minEast);
+                if (r.next == kSegSelf) { closed = true; break; }
+                if (!valid_id(r.next)) { ok = false; break; }
+                if (r.next < nSeeds) { firstSeed = r.next; break; }
+                id = r.next;  // a continuation of the candidate's own stretch
+            }
+            if (ok && closed) {
+                len = own;
+            } else if (ok) {
+                // once round the ring of seed records
+                uint32_t ring = 0;
+                id = firstSeed;
+                for (unsigned int hop = 0;; hop++) {
+                    const SegRec r = seg[id];
+                    if (r.next == kSegNone || r.next == kSegAbort || r.next == kSegSelf || r.len > (uint32_t)kSegLen || !valid_id(r.next) ||
+                        hop > hopCap) { ok = false; break; }
+                    ring += r.len;
+                    nrec++;
+                    minAll = min(minAll, r.minAll);
+                    minEast = min(minEast, r.minEast);
+                    if (ring > (uint32_t)cfg.maxPerim || (isHole ? minEast : minAll) < startKey) { ok = false; break; }
+                    id = r.next;
+                    if (id == firstSeed) break;
                 }
+                len = ring;
+                if (ok && own > ring) ok = false;  // (cannot happen: the candidate lies on the ring)
             }
+            if (ok && (isHole ? minEast : minAll) < startKey) ok = false;  // a crack with a smaller key: not the canonical start
+            if (ok && (len < (uint32_t)cfg.minPerim || len > (uint32_t)cfg.maxPerim)) ok = false;
         }
-
-        // ---- a lane about to take step 0, 256, 512, ... starts a piece: a chain chunk, and the pixel it starts at ----
-        {
-            const bool newPiece = active && (count & (kCkStride - 1)) == 0;
-            const unsigned long long bal = __ballot(newPiece);
-            if (bal) {
-                uint2 unused;
-                const unsigned int base = chainA.take((unsigned int)__popcll(bal), kChainBlock, &ctr->nChain, chainCap, 256u, ctr, lane, unused);
-                if (newPiece) {
-                    chChunk = base == ~0u ? ~0u : base + (unsigned int)__popcll(bal & ((1ull << lane) - 1ull));
-                    chFail = chFail || base == ~0u;
-                    chAcc = 0;
-                    chWords = chain + (size_t)(chChunk == ~0u ? 0u : chChunk) * 32;
-                    myCk[(count / kCkStride) & (kCkMax - 1)] = make_uint2((uint32_t)cx | ((uint32_t)cy << 16), chChunk);
-                }
-            }
-        }
-
-        // res: -1 keep going, 0 drop, > 0 the border closed with that many points
-        int res = -1;
-        if (active) {
-            // One step, forward (T) or backward (T^-1), on one branch-free code path (this chain of dependent
-            // instructions, times the length of the longest border, bounds the kernel).
-            //   forward : from (P, s) sweep counter-clockwise from s + 1 to the first foreground neighbour d;
-            //             the pixel counted is P, the new state is (P + d, d + 4).
-            //   backward: at pixel P whose forward successor lies in direction s, the predecessor p is the
-            //             first foreground neighbour clockwise from s - 1; bit-reversing the mask turns
-            //             clockwise into increasing bit numbers.  The state completed is (P, p).
-            const uint32_t m = win.mask(tile, lane, cx, cy);
-            const uint32_t mm = bw ? (__brev(m) >> 24) : m;   // backward: bit b <-> direction 7 - b
-            const int b0 = (bw ? 8 - s : s + 1) & 7;           // first bit looked at
-            const uint32_t rot = ((mm >> b0) | (mm << (8 - b0))) & 0xFFu;
-            const int j = __builtin_ctz(rot | 0x100u);         // zeros swept (m always holds a neighbour)
-            const int q = (bw ? s - 1 - j : s + 1 + j) & 7;    // direction found: p or d
-            // the sweep passed the east neighbour: forward s + 1 + j >= 9, backward 1 <= s <= j
-            const bool east = (unsigned int)(bw ? s - 1 : 7 - s) < (unsigned int)j;
-            const int key = (int)__umul24((unsigned int)cy, (unsigned int)W) + cx;
-            const bool abort = (!isHole || east) && key < startKey;  // smaller key: not the canonical start
-            const uint32_t here = pack_state(cx, cy, bw ? q : s);
-            chAcc |= (uint32_t)q << (4 * (count & 7));           // step `count` goes in direction q
-            if ((count & 7) == 7) {
-                if (chChunk != ~0u) chWords[(count >> 3) & 31] = chAcc;
-                chAcc = 0;
-            }
-            count++;
-            cx += fast_dx(q);
-            cy += fast_dy(q);
-            s = q ^ 4;
-            const uint32_t newState = bw ? here : pack_state(cx, cy, s);
-            // ---- the pair compares notes (both lanes of a pair are active or idle together) ----
-            const uint32_t pNew = from_partner(newState | (abort ? 0x80000000u : 0u));
-            const uint32_t pOld = from_partner(prevState);
-            const bool anyAbort = abort || (pNew >> 31);
-            const uint32_t pn = pNew & 0x7FFFFFFFu;
-            const bool met = pn == newState;                                         // every state counted once
-            const bool crossed = (bw ? pn : newState) == (bw ? prevState : pOld);   // one pixel counted twice
-            const int total = 2 * count - (met ? 0 : 1);
-            res = (met || crossed) ? (total > cfg.maxPerim ? 0 : total)
-                                   : (2 * count - 1 > cfg.maxPerim ? 0 : -1);  // more points than allowed whatever follows
-            if (anyAbort) res = 0;
-            prevState = newState;
-        }
-        // ---- accepted borders: the wave hands out space border by border (uniform loop), then the pair writes ----
-        // (a pair that could not get a chain chunk is dropped: the call fails with CAMSYNC_E_CAPACITY anyway)
-        const bool pairFail = chFail || from_partner(chFail ? 1u : 0u) != 0u;
-        const bool accept = res >= cfg.minPerim && res <= cfg.maxPerim && !pairFail;
-        const unsigned int nt = (unsigned int)((count + kCkStride - 1) / kCkStride);  // pieces of this lane's half
+        // ---- the wave hands out space border by border (uniform loop) ----
         unsigned int myOff = ~0u, mySlot = ~0u, myTask = ~0u;
-        unsigned long long am = __ballot(accept && !bw);
+        unsigned long long am = __ballot(have && ok);
         while (am) {
             const int l = __ffsll((long long)am) - 1;
             am &= am - 1;
-            const unsigned int len = (unsigned int)__builtin_amdgcn_readlane(res, l), ntl = (unsigned int)__builtin_amdgcn_readlane((int)nt, l);
+            const unsigned int ll = (unsigned int)__builtin_amdgcn_readlane((int)len, l), nr = (unsigned int)__builtin_amdgcn_readlane((int)nrec, l);
             uint2 left;
-            const unsigned int off = poolA.take(len, kPoolBlock, &ctr->nPool, poolCap, 4u, ctr, lane, left);
+            const unsigned int off = poolA.take(ll, kPoolBlock, &ctr->nPool, poolCap, 4u, ctr, lane, left);
             const unsigned int slot = slotA.take(1, kSlotBlock, &ctr->nContours, contourCap, 2u, ctr, lane, left);
-            const unsigned int t0 = taskA.take(2 * ntl, kTaskBlock, &ctr->nCopy, taskCap, 64u, ctr, lane, left);
+            const unsigned int t0 = taskA.take(nr, kTaskBlock, &ctr->nCopy, taskCap, 64u, ctr, lane, left);
             mark_empty_tasks(tasks, left.x, left.y, lane);
             if (off == ~0u || slot == ~0u || t0 == ~0u) {
-                // a list is full (the call will fail with CAMSYNC_E_CAPACITY): what was obtained must still read
-                // as empty, the later passes look at every reserved entry
                 if (slot != ~0u) mark_empty_contours(contours, slot, slot + 1, lane);
-                if (t0 != ~0u) mark_empty_tasks(tasks, t0, t0 + 2 * ntl, lane);
+                if (t0 != ~0u) mark_empty_tasks(tasks, t0, t0 + nr, lane);
                 adopt_orphans(slotA, taskA, contours, tasks, lane);
             }
-            if ((lane & ~1) == l && off != ~0u && slot != ~0u && t0 != ~0u) {
+            if (lane == l && off != ~0u && slot != ~0u && t0 != ~0u) {
                 myOff = off;
                 mySlot = slot;
-                myTask = t0 + (bw ? ntl : 0u);
+                myTask = t0;
             }
         }
-        if (res >= 0) {
-            active = false;
-            if (accept && myOff != ~0u) {
-                if (!bw) {
-                    const uint32_t pos = (uint32_t)(c & 0xFFFFFFFFull);
-                    ContourRec r;
-                    r.frame = (uint32_t)(c >> 40);
-                    r.pos = pos;
-                    r.len = (uint32_t)res;
-                    r.off = myOff;
-                    r.scale = (uint16_t)((c >> 36) & 7u);
-                    r.hole = isHole ? 1 : 0;
-                    r.scanKey = pos + (isHole ? 1u : 0u);
-                    contours[mySlot] = r;
-                }
-                // the steps of the last, partly filled word
-                if ((count & 7) != 0 && chChunk != ~0u) chWords[((count - 1) >> 3) & 31] = chAcc;
-                // One copy task per piece.  The forward lane's pixels are points 0 .. count - 1 of the contour; the
-                // backward lane's pixel after m steps is point res - 1 - m (its states B_1 .. B_count are points
-                // res - 1 .. res - count).
-                for (unsigned int t = 0; t < nt; t++) {
-                    const uint2 piece = myCk[t];
-                    const unsigned int np = min((unsigned int)kCkStride, (unsigned int)count - t * kCkStride);
-                    CopyTask k;
-                    k.chunk = piece.y;
-                    k.start = piece.x;
-                    k.dst = bw ? myOff + (unsigned int)res - 1u - t * kCkStride : myOff + t * kCkStride;
-                    k.n = np | (bw ? 0x80000000u : 0u);
-                    tasks[myTask + t] = k;
-                }
+        // ---- pass 2: the record and one copy task per segment, in border order ----
+        if (have && ok && myOff != ~0u) {
+            const uint32_t pos = (uint32_t)(c & 0xFFFFFFFFull);
+            ContourRec r;
+            r.frame = (uint32_t)(c >> 40);
+            r.pos = pos;
+            r.len = len;
+            r.off = myOff;
+            r.scale = (uint16_t)((c >> 36) & 7u);
+            r.hole = isHole ? 1 : 0;
+            r.scanKey = pos + (isHole ? 1u : 0u);
+            contours[mySlot] = r;
+            uint32_t emitted = 0, t = 0, id = nSeeds + i;
+            for (unsigned int hop = 0; hop < nrec; hop++) {
+                const SegRec sr = seg[id];
+                const uint32_t n = min(sr.len, len - emitted);
+                CopyTask k;
+                k.chunk = sr.chunk;
+                k.start = sr.start;
+                k.dst = myOff + emitted;
+                k.n = n;  // (n = 0 reads as an empty task)
+                tasks[myTask + t++] = k;
+                emitted += n;
+                id = sr.next;
+                if (id == kSegSelf) break;
             }
+            // (tasks reserved beyond the ones written cannot exist: pass 1 counted the same records)
         }
     }
-    // entries reserved but never used must read as empty
     mark_empty_contours(contours, slotA.cur, slotA.end, lane);
     mark_empty_tasks(tasks, taskA.cur, taskA.end, lane);
 }
@@ -1123,22 +1290,26 @@ void launch_contour_starts(const DetCfg& c, const DetBuffers& b, int B, hipStrea
     bands = (totalGroups + bandGroups - 1) / bandGroups;
     const long long grid = waves * bands;
     hipLaunchKernelGGL(k_contour_starts, dim3((unsigned)grid), dim3(64), 0, st, b.planes, c, B, bands, bandGroups, b.cand, b.candCap,
-                       b.counters);
+                       b.seeds, b.seedCap, b.counters);
 }
 
 void launch_trace(const DetCfg& c, const DetBuffers& b, hipStream_t st) {
     hipLaunchKernelGGL(k_trace_short, dim3(256 * 8), dim3(256), 0, st, b.planes, c, b.cand, b.candCap, b.candLong,
                        b.contours, b.contourCap, b.poolCap, b.tasks, b.taskCap, b.counters);
-    // the long-border kernels are persistent: 16 single-wave workgroups per CU (8 KiB of LDS each)
     debug_stage(st, "trace_short");
-    // (the start list is free after the short pass: it holds the tail records)
-    TailRec* tail = reinterpret_cast<TailRec*>(b.cand);
-    hipLaunchKernelGGL(k_trace_decide<false>, dim3(kTraceWaves), dim3(64), 0, st, b.planes, c, b.candLong, b.candCap, tail,
-                       b.contours, b.contourCap, b.poolCap, b.copies, b.copyCap, b.ckpt, b.chain, b.chainCap, b.counters);
-    debug_stage(st, "trace_decide");
-    hipLaunchKernelGGL(k_trace_decide<true>, dim3(kTraceWaves * kTailPairs * 2 / kTailLanes), dim3(64), 0, st, b.planes, c, b.candLong,
-                       b.candCap, tail, b.contours, b.contourCap, b.poolCap, b.copies, b.copyCap, b.ckpt, b.chain, b.chainCap, b.counters);
-    debug_stage(st, "trace_decide_tail");
+    // long borders: seeds -> table, segments (persistent: 16 single-wave workgroups per CU, 8 KiB of LDS each), decision
+    hipLaunchKernelGGL(k_seed_hash, dim3(256 * 4), dim3(256), 0, st, b.seeds, b.seedCap, c.nScales, b.hashKeys, b.hashVals, b.hashMask,
+                       b.counters);
+    debug_stage(st, "seed_hash");
+    hipLaunchKernelGGL(k_seg_walk, dim3(kTraceWaves), dim3(64), 0, st, b.planes, c, b.seeds, b.seedCap, b.candLong, b.candCap, b.seg,
+                       b.segCap, b.chain, b.counters);
+    debug_stage(st, "seg_walk");
+    hipLaunchKernelGGL(k_seg_link, dim3(256 * 8), dim3(256), 0, st, b.seg, b.segCap, b.seedCap, b.candCap, c.nScales, b.hashKeys,
+                       b.hashVals, b.hashMask, b.counters);
+    debug_stage(st, "seg_link");
+    hipLaunchKernelGGL(k_resolve, dim3(256 * 32), dim3(64), 0, st, c, b.candLong, b.candCap, b.seedCap, b.seg, b.segCap, b.contours,
+                       b.contourCap, b.poolCap, b.copies, b.copyCap, b.counters);
+    debug_stage(st, "resolve");
     // points of the borders the short pass kept (followed once more from their start), then of the long ones
     hipLaunchKernelGGL(k_trace_store, dim3(256 * 4), dim3(64), 0, st, b.planes, c, b.tasks, b.taskCap, b.pool, b.poolCap, b.counters);
     debug_stage(st, "trace_store");

@@ -121,9 +121,9 @@ int camsync_detect_batch(camsync_ctx* ctx, const uint8_t* frames, int on_device,
 int camsync_debug_counts(camsync_ctx* ctx, int frame, int32_t out[8]);
 /* Fill level and capacity of the chunk-wide scratch lists after the last chunk (capacity planning; a list that is
  * fuller than its capacity made the call fail with CAMSYNC_E_CAPACITY): [0] contour-start candidates, [1] candidates
- * of the long-border pass, [2] contour records, [3] contour points, [4] store tasks (short borders), [5] chain
- * chunks (128 bytes per 256 steps of a long border), [6] copy tasks, [7] borders handed to the tail pass.  The
- * counters include the blocks the border-follower waves reserve and leave partly unused. */
+ * of the long-border pass, [2] contour records, [3] contour points, [4] store tasks (short borders), [5] border
+ * segments (a record and a 128-byte chain chunk each), [6] copy tasks, [7] border seeds.  The counters include the
+ * blocks the border-follower waves reserve and leave partly unused. */
 int camsync_debug_lists(camsync_ctx* ctx, uint32_t used[8], uint32_t cap[8]);
 /* The threshold image of `frame` at `scale` as the detection pipeline of the last chunk produced it (one bit per
  * pixel on the device; here one byte per pixel, 0 or 1, [H,W]): cv.adaptiveThreshold(MEAN_C, BINARY_INV) with the
