@@ -816,8 +816,12 @@ __global__ __launch_bounds__(64) void k_seg_walk(const uint32_t* __restrict__ pl
     const int H = cfg.H, W = cfg.W, WS = cfg.WS, S = cfg.nScales;
     const size_t perPlane = plane_words(H, WS);
 
-    // walking: following a border; ended: a segment is complete and waits for the service phase to write its record
-    bool walking = false, ended = false, goesOn = false, fresh = false, isCand = false, isHole = false;
+    // Lane state, kept in vector registers as plain integers so that the step below compiles to straight-line code
+    // with selects (per-lane booleans that live across iterations end up as scalar mask pairs, and every `if` on them
+    // as a chain of scalar mask instructions: that doubled the instruction count of a step).
+    //   st: 0 idle, 1 following a border, 2 segment complete (the service phase writes its record), 3 segment
+    //       complete and the lane goes on in a continuation segment
+    int st = 0, isCand = 0, isHole = 0, fresh = 0;
     uint64_t c = 0, nextC = 0;
     uint32_t nextI = ~0u;   // the item this lane takes up next (~0u: none fetched)
     bool exhausted = false;  // the queue has nothing more for this lane
@@ -838,8 +842,9 @@ __global__ __launch_bounds__(64) void k_seg_walk(const uint32_t* __restrict__ pl
     for (unsigned int iter = 0;; iter++) {
         if (iter % kService == 0) {
             // ---- finished segments: record, continuation ----
-            if (ended) {
+            if (st >= 2) {
                 uint32_t cont = 0, next = endNext;
+                bool goesOn = st == 3;
                 if (goesOn) {
                     const unsigned int v = atomicAdd(&ctr->nVirt, 1u);
                     // continuation ids count down from the top of the record list, work items up from its bottom
@@ -859,15 +864,14 @@ __global__ __launch_bounds__(64) void k_seg_walk(const uint32_t* __restrict__ pl
                 r.pad0 = endKey;
                 r.pad1 = (uint32_t)(c >> 36);  // frame << 4 | hole << 3 | scale
                 seg[id] = r;
-                ended = false;
+                st = 0;
                 if (goesOn) {
                     id = cont;
                     count = 0;
                     minAll = minEast = 0xFFFFFFFFu;
                     startPix = (uint32_t)cx | ((uint32_t)cy << 16);
                     chAcc = 0;
-                    walking = true;
-                    goesOn = false;
+                    st = 1;
                 }
             }
             // ---- lanes without a next item draw one (its load is in flight while the current item is followed) ----
@@ -884,16 +888,16 @@ __global__ __launch_bounds__(64) void k_seg_walk(const uint32_t* __restrict__ pl
                 }
             }
             // ---- idle lanes take up their next item ----
-            if (!walking && nextI != ~0u) {
+            if (st == 0 && nextI != ~0u) {
                 c = nextC;
                 id = nextI;
                 nextI = ~0u;
-                isCand = id >= nSeeds;
+                isCand = id >= nSeeds ? 1 : 0;
                 const uint32_t pos = (uint32_t)(c & 0xFFFFFFFFull);
                 plane = planes + ((size_t)(uint32_t)(c >> 40) * S + (int)((c >> 36) & 7u)) * perPlane;
                 cx = (int)(pos % W);
                 cy = (int)(pos / W);
-                isHole = isCand && ((c >> 39) & 1u);
+                isHole = isCand & (int)((c >> 39) & 1u);
                 startKey = cy * W + cx;
                 minAll = minEast = 0xFFFFFFFFu;
                 if (!isCand) {
@@ -906,76 +910,61 @@ __global__ __launch_bounds__(64) void k_seg_walk(const uint32_t* __restrict__ pl
                 startPix = (uint32_t)cx | ((uint32_t)cy << 16);
                 chAcc = 0;
                 win.valid = false;
-                walking = true;
+                st = 1;
                 fresh = isCand;
             }
-            if (!__any(walking)) {
+            if (!__any(st == 1)) {
                 if (__all(exhausted && nextI == ~0u)) break;
                 continue;
             }
             // ---- windows ----
-            if (__any(walking && win.near_edge(cx, cy))) {
-                if (walking && win.near_edge(cx, cy)) win.recentre(plane, WS, H, cx, cy, tile, lane);
+            if (__any(st == 1 && win.near_edge(cx, cy))) {
+                if (st == 1 && win.near_edge(cx, cy)) win.recentre(plane, WS, H, cx, cy, tile, lane);
             }
         }
-        if (walking && win.covers(cx, cy)) {  // (always covered, see above; a lane that is not waits for the next phase)
+        if (st == 1 && win.covers(cx, cy)) {  // (always covered, see above; a lane that is not waits for the next phase)
             const uint32_t m = win.mask(tile, lane, cx, cy);
-            if (fresh) {  // a start candidate takes its start state (P0, s0)
-                const int s0 = fresh_dir(m, isHole);  // never -1: single pixels end in the short pass
-                s = s0 < 0 ? 0 : s0;
-                state0 = pack_state(cx, cy, s);
-                fresh = false;
-            }
+            // a start candidate takes its start state (P0, s0) (s0 is never -1: single pixels end in the short pass)
+            const int s0 = fresh_dir(m, isHole != 0);
+            s = fresh ? (s0 < 0 ? 0 : s0) : s;
+            state0 = fresh ? pack_state(cx, cy, s) : state0;
+            fresh = 0;
             // sweep counter-clockwise from s + 1 to the first foreground neighbour q; j background pixels are passed
             const int b0 = (s + 1) & 7;
             const uint32_t rot = ((m >> b0) | (m << (8 - b0))) & 0xFFu;
             const int j = __builtin_ctz(rot | 0x100u);
             const int q = (s + 1 + j) & 7;
-            // position of direction `dir` in the sweep: passed when 1 <= t <= j
+            // position of a direction in the sweep: passed when 1 <= t <= j
             const int sd = seed_dir(cx, cy);
             const int tSeed = (sd - s) & 7, tEast = (0 - s) & 7;
-            const bool east = (unsigned int)(tEast - 1) < (unsigned int)j;
-            const bool atSeed = sd >= 0 && (unsigned int)(tSeed - 1) < (unsigned int)j && seed_supported(m, sd);
+            const int east = (unsigned int)(tEast - 1) < (unsigned int)j ? 1 : 0;
+            const uint32_t supA = (sd & 2) ? 0x38u : 0x0Eu, supB = (sd & 2) ? 0x83u : 0xE0u;  // both sides of the crack
+            const int atSeed = (sd >= 0 ? 1 : 0) & ((unsigned int)(tSeed - 1) < (unsigned int)j ? 1 : 0) & ((m & supA) ? 1 : 0) & ((m & supB) ? 1 : 0);
             const uint32_t key = (uint32_t)(cy * W + cx);
-            if (atSeed) {
-                // the seed's own segment accounts for this pixel, but it starts its sweep behind the crack: an east
-                // crack passed before the seed's crack in this same sweep is accounted for here
-                if (east && tEast < tSeed) minEast = min(minEast, key);
-                endNext = kSegPending;
-                endKey = key;
-                ended = true;
-                walking = false;
-            } else if (isCand && (!isHole || east) && (int)key < startKey) {  // not the canonical start
-                endNext = kSegAbort;
-                ended = true;
-                walking = false;
-            } else {
-                minAll = min(minAll, key);
-                if (east) minEast = min(minEast, key);
-                chAcc |= (uint32_t)q << (4 * (count & 7));
-                if ((count & 7) == 7) {
-                    chain[(size_t)id * 32 + ((count >> 3) & 31)] = chAcc;
-                    chAcc = 0;
-                }
-                count++;
-                total++;
-                cx += fast_dx(q);
-                cy += fast_dy(q);
-                s = q ^ 4;
-                if (isCand && pack_state(cx, cy, s) == state0) {  // a border without seeds closed
-                    endNext = kSegSelf;
-                    ended = true;
-                    walking = false;
-                } else if (isCand && total > (uint32_t)cfg.maxPerim) {
-                    endNext = kSegAbort;
-                    ended = true;
-                    walking = false;
-                } else if (count == (uint32_t)kSegLen) {  // goes on in a continuation segment
-                    ended = true;
-                    goesOn = true;
-                    walking = false;
-                }
+            // a start candidate that meets a crack with a smaller key is not the canonical start
+            const int abortNow = isCand & ((isHole ^ 1) | east) & ((int)key < startKey ? 1 : 0) & (atSeed ^ 1);
+            const int emit = (atSeed | abortNow) ^ 1;
+            // the seed's own segment accounts for the seed pixel, but it starts its sweep behind the crack: an east
+            // crack passed before the seed's crack in this same sweep is accounted for here
+            const int eastHere = (emit & east) | (atSeed & east & (tEast < tSeed ? 1 : 0));
+            minEast = eastHere ? min(minEast, key) : minEast;
+            minAll = emit ? min(minAll, key) : minAll;
+            chAcc |= emit ? (uint32_t)q << (4 * (count & 7)) : 0u;
+            if (emit && (count & 7) == 7) {
+                chain[(size_t)id * 32 + ((count >> 3) & 31)] = chAcc;
+                chAcc = 0;
             }
+            count += (uint32_t)emit;
+            total += (uint32_t)emit;
+            cx += emit ? fast_dx(q) : 0;
+            cy += emit ? fast_dy(q) : 0;
+            s = emit ? (q ^ 4) : s;
+            const int closed = emit & isCand & (pack_state(cx, cy, s) == state0 ? 1 : 0);  // a border without seeds closed
+            const int tooLong = emit & isCand & (total > (uint32_t)cfg.maxPerim ? 1 : 0) & (closed ^ 1);
+            const int full = emit & (count == (uint32_t)kSegLen ? 1 : 0) & ((closed | tooLong) ^ 1);
+            endNext = atSeed ? kSegPending : (abortNow | tooLong) ? kSegAbort : closed ? kSegSelf : endNext;
+            endKey = atSeed ? key : endKey;
+            st = (atSeed | abortNow | closed | tooLong) ? 2 : full ? 3 : 1;
         }
     }
 }
