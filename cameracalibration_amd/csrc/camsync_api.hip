@@ -67,9 +67,9 @@ struct camsync_ctx {
     CalibState cal{};
     float *d_calObj = nullptr, *d_calImg = nullptr;
     double* d_calWork = nullptr;   // [CAMSYNC_CALIB_WORK_DOUBLES]: acc | focal sums | trial record | delta | flag (see kW*)
-    double* d_calDelta = nullptr;  // = d_calWork + kWDelta
     double* d_focalRows = nullptr;
-    double* d_focalAcc = nullptr;  // = d_calWork + kWFocal
+    size_t calCapPts = 0, calCapV = 0;  // what the calibration buffers were sized for
+    int calCapNI = 0;
     double* h_pin = nullptr;       // pinned host doubles for the small read-backs of the LM loop
     // pinned host copies of a chunk's detection results (allocated on first use, kept for the context's life)
     int32_t *h_ids = nullptr, *h_counts = nullptr, *h_rejCounts = nullptr;
@@ -131,8 +131,7 @@ unsigned char* scratch_for_device(int device, hipError_t* err) {
 
 // layout of the calibration work buffer (doubles); everything that is summed over ranks lives here, so that a
 // caller-provided buffer (e.g. a torch tensor) can be handed to the collective
-constexpr int kWAcc = 0, kWFocal = 160, kWRec = 168, kWDelta = 176, kWFlag = 190;
-static_assert(kWFlag < CAMSYNC_CALIB_WORK_DOUBLES && 12 * 12 + 12 + 1 <= kWFocal, "work buffer layout");
+static_assert(kWDelta + 12 <= CAMSYNC_CALIB_WORK_DOUBLES && 12 * 12 + 12 + 3 <= kWFocal, "work buffer layout");
 
 int fail(camsync_ctx* c, int code, const char* fmt, ...) {
     if (c) {
@@ -531,7 +530,7 @@ void camsync_destroy(camsync_ctx* c) {
                     b.outIds, b.outCorners, b.rawCorners, b.outCounts, b.outRejected, b.outRejCounts, c->d_dict, c->d_expTab,
                     c->d_obj, c->d_img, c->d_npts, c->d_K, c->d_dist, c->d_rvec, c->d_tvec, c->d_mae, c->d_rmse, c->d_ok,
                     c->d_anchorIds, c->d_anchorObj, c->d_calObj, c->d_calImg, c->cal.intr, c->cal.ext, c->cal.intrTrial,
-                    c->cal.extTrial, c->cal.viewBlocks, c->cal.partial, c->cal.errPartial,
+                    c->cal.extTrial, c->cal.viewBlocks, c->cal.viewBlocksTrial, c->cal.partial, c->cal.ticket,
                     c->d_calWork, c->d_focalRows, c->d_calOk, c->d_calK, c->d_calNpts};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -1262,49 +1261,53 @@ int camsync_calib_begin(camsync_ctx* c, const float* obj, const float* img, int 
         return fail(c, CAMSYNC_E_ARG, "calibration needs 4..64 points per view (one wavefront lane per point)");
     HIPCHK(c, hipSetDevice(c->device));
     CalibState& s = c->cal;
-    void* old[] = {c->d_calObj, c->d_calImg, s.intr, s.ext, s.intrTrial, s.extTrial, s.viewBlocks, s.partial,
-                   s.errPartial, c->d_calWork, c->d_focalRows, c->d_calOk, c->d_calK, c->d_calNpts};
-    for (void* p : old)
-        if (p) (void)hipFree(p);
-    c->d_calObj = c->d_calImg = nullptr;
-    c->d_calWork = c->d_focalRows = c->d_calK = nullptr;
-    c->d_calOk = nullptr;
-    c->d_calNpts = nullptr;
-    c->calReady = false;
-    s = CalibState{};
+    const int NI = (flags & 1) ? 12 : 9;
+    const size_t nv = (size_t)std::max(V, 1);
+    // the buffers of the last problem are kept while they are large enough (repeated calibrations allocate nothing)
+    if (!(c->calReady && nv * P <= c->calCapPts && nv <= c->calCapV && NI <= c->calCapNI)) {
+        void* old[] = {c->d_calObj, c->d_calImg, s.intr, s.ext, s.intrTrial, s.extTrial, s.viewBlocks, s.viewBlocksTrial, s.partial,
+                       s.ticket, c->d_calWork, c->d_focalRows, c->d_calOk, c->d_calK, c->d_calNpts};
+        for (void* p : old)
+            if (p) (void)hipFree(p);
+        c->d_calObj = c->d_calImg = nullptr;
+        c->d_calWork = c->d_focalRows = c->d_calK = nullptr;
+        c->d_calOk = nullptr;
+        c->d_calNpts = nullptr;
+        c->calReady = false;
+        s = CalibState{};
+        HIPCHK(c, dalloc(&c->d_calObj, nv * P * 3));
+        HIPCHK(c, dalloc(&c->d_calImg, nv * P * 2));
+        HIPCHK(c, dalloc(&s.intr, 12));
+        HIPCHK(c, dalloc(&s.ext, nv * 6));
+        HIPCHK(c, dalloc(&s.intrTrial, 12));
+        HIPCHK(c, dalloc(&s.extTrial, nv * 6));
+        HIPCHK(c, dalloc(&s.viewBlocks, nv * (6 * NI + 6)));
+        HIPCHK(c, dalloc(&s.viewBlocksTrial, nv * (6 * NI + 6)));
+        HIPCHK(c, dalloc(&s.partial, (size_t)(calib_lm_grid((int)nv) + 32) * 160));
+        HIPCHK(c, dalloc(&s.ticket, 33));
+        HIPCHK(c, hipMemset(s.ticket, 0, sizeof(unsigned int) * 33));
+        HIPCHK(c, dalloc(&c->d_calWork, (size_t)CAMSYNC_CALIB_WORK_DOUBLES));
+        HIPCHK(c, dalloc(&c->d_focalRows, nv * 6));
+        HIPCHK(c, dalloc(&c->d_calOk, nv));
+        HIPCHK(c, dalloc(&c->d_calK, 9 + 8));
+        HIPCHK(c, dalloc(&c->d_calNpts, nv));
+        c->calCapPts = nv * P;
+        c->calCapV = nv;
+        c->calCapNI = NI;
+    }
     s.V = V;
     s.P = P;
-    s.NI = (flags & 1) ? 12 : 9;
-    const int L = s.NI * s.NI + s.NI + 1;
-    const size_t nv = (size_t)std::max(V, 1);
-    HIPCHK(c, dalloc(&c->d_calObj, nv * P * 3));
-    HIPCHK(c, dalloc(&c->d_calImg, nv * P * 2));
-    HIPCHK(c, dalloc(&s.intr, 12));
-    HIPCHK(c, dalloc(&s.ext, nv * 6));
-    HIPCHK(c, dalloc(&s.intrTrial, 12));
-    HIPCHK(c, dalloc(&s.extTrial, nv * 6));
-    HIPCHK(c, dalloc(&s.viewBlocks, nv * (6 * s.NI + 6)));
-    HIPCHK(c, dalloc(&s.partial, nv * L));
-    (void)L;
-    HIPCHK(c, dalloc(&c->d_calWork, (size_t)CAMSYNC_CALIB_WORK_DOUBLES));
-    HIPCHK(c, hipMemset(c->d_calWork, 0, sizeof(double) * CAMSYNC_CALIB_WORK_DOUBLES));
-    s.acc = c->d_calWork + kWAcc;
-    s.errOut = c->d_calWork + kWRec;
-    c->d_calDelta = c->d_calWork + kWDelta;
-    c->d_focalAcc = c->d_calWork + kWFocal;
-    HIPCHK(c, dalloc(&s.errPartial, nv));
-    HIPCHK(c, dalloc(&c->d_focalRows, nv * 6));
-    HIPCHK(c, dalloc(&c->d_calOk, nv));
-    HIPCHK(c, dalloc(&c->d_calK, 9 + 8));
-    HIPCHK(c, dalloc(&c->d_calNpts, nv));
+    s.NI = NI;
+    HIPCHK(c, hipMemsetAsync(c->d_calWork, 0, sizeof(double) * CAMSYNC_CALIB_WORK_DOUBLES, c->stream));
     if (V > 0) {
-        HIPCHK(c, hipMemcpy(c->d_calObj, obj, sizeof(float) * (size_t)V * P * 3, hipMemcpyHostToDevice));
-        HIPCHK(c, hipMemcpy(c->d_calImg, img, sizeof(float) * (size_t)V * P * 2, hipMemcpyHostToDevice));
-        std::vector<int32_t> np(V, P);
-        HIPCHK(c, hipMemcpy(c->d_calNpts, np.data(), sizeof(int32_t) * V, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpyAsync(c->d_calObj, obj, sizeof(float) * (size_t)V * P * 3, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->d_calImg, img, sizeof(float) * (size_t)V * P * 2, hipMemcpyHostToDevice, c->stream));
+        launch_fill_i32(c->d_calNpts, V, P, c->stream);
+        HIPCHK(c, hipGetLastError());
     }
-    HIPCHK(c, hipMemset(s.intr, 0, sizeof(double) * 12));
-    HIPCHK(c, hipMemset(s.ext, 0, sizeof(double) * nv * 6));
+    HIPCHK(c, hipMemsetAsync(s.intr, 0, sizeof(double) * 12, c->stream));
+    HIPCHK(c, hipMemsetAsync(s.ext, 0, sizeof(double) * nv * 6, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // obj / img are the caller's again
     s.obj = c->d_calObj;
     s.img = c->d_calImg;
     c->calReady = true;
@@ -1319,9 +1322,9 @@ int camsync_calib_focal_acc(camsync_ctx* c, int W, int H, double acc6[6]) {
     for (int i = 0; i < 6; i++) acc6[i] = 0;
     if (c->cal.V == 0) return CAMSYNC_OK;
     const double cx = (!W) ? 0.5 : (W - 1) * 0.5, cy = (!H) ? 0.5 : (H - 1) * 0.5;
-    launch_calib_focal_rows(c->cal, cx, cy, c->d_focalRows, c->d_focalAcc, c->stream);
+    launch_calib_focal_rows(c->cal, cx, cy, c->d_focalRows, c->d_calWork + kWFocal, c->stream);
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(acc6, c->d_focalAcc, sizeof(double) * 6, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(acc6, c->d_calWork + kWFocal, sizeof(double) * 6, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return CAMSYNC_OK;
 }
@@ -1356,13 +1359,9 @@ int camsync_calib_accumulate(camsync_ctx* c, double lambda, double* acc, int acc
     HIPCHK(c, hipSetDevice(c->device));
     CalibState& s = c->cal;
     const int L = s.NI * s.NI + s.NI + 1;
-    if (s.V > 0) {
-        launch_calib_accumulate(s, lambda, c->stream);
-        HIPCHK(c, hipGetLastError());
-    } else {
-        HIPCHK(c, hipMemsetAsync(s.acc, 0, sizeof(double) * L, c->stream));
-    }
-    HIPCHK(c, hipMemcpyAsync(acc, s.acc, sizeof(double) * L, acc_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
+    launch_calib_lm(s, 0, lambda, c->d_calWork, c->stream);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(acc, c->d_calWork + kWAcc, sizeof(double) * L, acc_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return CAMSYNC_OK;
 }
@@ -1412,24 +1411,26 @@ int camsync_calib_step(camsync_ctx* c, const double* delta, double* err_out) {
     if (!c || !c->calReady || !delta || !err_out) return CAMSYNC_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     CalibState& s = c->cal;
-    HIPCHK(c, hipMemcpyAsync(c->d_calDelta, delta, sizeof(double) * s.NI, hipMemcpyHostToDevice, c->stream));
-    launch_calib_backsub(s, c->d_calDelta, c->stream);
-    *err_out = 0;
-    if (s.V > 0) {
-        launch_calib_error(s, 1, c->stream);
-        HIPCHK(c, hipGetLastError());
-        HIPCHK(c, hipMemcpyAsync(err_out, s.errOut, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    }
+    const int L = s.NI * s.NI + s.NI + 1;
+    HIPCHK(c, hipMemcpyAsync(c->d_calWork + kWDelta, delta, sizeof(double) * s.NI, hipMemcpyHostToDevice, c->stream));
+    // the trial parameters' record is formed as well (undamped, unused here); the error is its last entry
+    launch_calib_lm(s, 2, 0.0, c->d_calWork, c->stream);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(err_out, c->d_calWork + kWAcc + L - 1, sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return CAMSYNC_OK;
 }
 
+// The trial parameters become the current ones: the three buffer pairs change roles.
+static void calib_swap(CalibState& s) {
+    std::swap(s.intr, s.intrTrial);
+    std::swap(s.ext, s.extTrial);
+    std::swap(s.viewBlocks, s.viewBlocksTrial);
+}
+
 int camsync_calib_accept(camsync_ctx* c) {
     if (!c || !c->calReady) return CAMSYNC_E_ARG;
-    HIPCHK(c, hipSetDevice(c->device));
-    launch_calib_accept(c->cal, c->stream);
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    calib_swap(c->cal);
     return CAMSYNC_OK;
 }
 
@@ -1465,23 +1466,8 @@ static int calibrate_impl(camsync_ctx* c, const float* obj, const float* img, in
     if (rc) return rc;
     CalibState& s = c->cal;
     const int NI = s.NI, L = NI * NI + NI + 1;
-    double* const work = d_work ? d_work : c->d_calWork;
-    if (d_work) {  // the records that cross ranks live in the caller's buffer for this call
-        HIPCHK(c, hipMemsetAsync(work, 0, sizeof(double) * CAMSYNC_CALIB_WORK_DOUBLES, c->stream));
-        s.acc = work + kWAcc;
-        s.errOut = work + kWRec;
-        c->d_calDelta = work + kWDelta;
-        c->d_focalAcc = work + kWFocal;
-    }
-    struct Restore {  // the building-block entry points keep working on the context's own buffer afterwards
-        camsync_ctx* c;
-        ~Restore() {
-            c->cal.acc = c->d_calWork + kWAcc;
-            c->cal.errOut = c->d_calWork + kWRec;
-            c->d_calDelta = c->d_calWork + kWDelta;
-            c->d_focalAcc = c->d_calWork + kWFocal;
-        }
-    } restore{c};
+    double* const work = d_work ? d_work : c->d_calWork;  // the records that cross ranks live in the caller's buffer
+    HIPCHK(c, hipMemsetAsync(work, 0, sizeof(double) * CAMSYNC_CALIB_WORK_DOUBLES, c->stream));
     auto allreduce = [&](double* p, int n) -> int {
         if (!ar) return CAMSYNC_OK;
         const int r = ar(user, p, n, (void*)c->stream);
@@ -1505,54 +1491,46 @@ static int calibrate_impl(camsync_ctx* c, const float* obj, const float* img, in
     rc = camsync_calib_set_intrinsics(c, intr, 1);
     if (rc) return rc;
 
-    auto accumulate = [&](int lambdaLg10) -> int {
-        const double lambda = exp(lambdaLg10 * log(10.));
-        if (V > 0) launch_calib_accumulate(s, lambda, c->stream);
-        else HIPCHK(c, hipMemsetAsync(s.acc, 0, sizeof(double) * L, c->stream));
-        return allreduce(s.acc, L);
-    };
-    // one trial step; afterwards hp[0] = error at the trial parameters, hp[1..4] = parameter change sums,
-    // hp[5] = solver flag, hp[6] = error at the current parameters (last entry of the reduced record)
-    auto trial = [&]() -> int {
-        launch_calib_solve(s, work + kWDelta, work + kWFlag, c->stream);
-        launch_calib_backsub(s, work + kWDelta, c->stream);
-        launch_calib_error(s, 1, c->stream);
-        launch_calib_change(s, work + kWRec, c->stream);
+    // One kernel and one all-reduce per trial step (k_calib.hip): the kernel that evaluates a trial also forms the
+    // trial parameters' record, damped as the next iteration will want it if the trial is accepted.
+    auto lambda_of = [](int lg10) { return exp(lg10 * log(10.)); };
+    auto evaluate = [&](int mode, int lg10) -> int {
+        launch_calib_lm(s, mode, lambda_of(lg10), work, c->stream);
         HIPCHK(c, hipGetLastError());
-        const int r = allreduce(work + kWRec, 3);
-        if (r) return r;
-        HIPCHK(c, hipMemcpyAsync(hp, work + kWRec, sizeof(double) * 5, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(hp + 5, work + kWFlag, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(hp + 6, s.acc + L - 1, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        if (hp[5] != 0.0) return fail(c, CAMSYNC_E_NUMERIC, "intrinsic block is singular");
-        return CAMSYNC_OK;
+        return allreduce(work + kWAcc, L + 2);
     };
-
     int lambdaLg10 = -3, it = 0;
     double prevErr = 0, errNorm = 0;
+    rc = evaluate(0, lambdaLg10);
+    if (rc) return rc;
     for (;;) {
-        rc = accumulate(lambdaLg10);
+        // trial step from the record at the current parameters; hp <- [err(trial), change sums | replicated values]
+        const int nextLg10 = std::max(lambdaLg10 - 1, -16);
+        rc = evaluate(1, nextLg10);
         if (rc) return rc;
-        for (;;) {
-            rc = trial();
+        // one read-back: [err(trial), change sums of the extrinsics ... change sums of the intrinsics, flag, old err]
+        HIPCHK(c, hipMemcpyAsync(hp, work + kWAcc + L - 1, sizeof(double) * (kWRec + 4 - (L - 1)), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        const double* const rep = hp + (kWRec - (L - 1));
+        if (rep[2] != 0.0) return fail(c, CAMSYNC_E_NUMERIC, "intrinsic block is singular");
+        if (it == 0) prevErr = rep[3];
+        errNorm = hp[0];
+        if (errNorm > prevErr && ++lambdaLg10 <= 16) {
+            // rejected: the same parameters with more damping
+            rc = evaluate(0, lambdaLg10);
             if (rc) return rc;
-            if (it == 0) prevErr = hp[6];
-            errNorm = hp[0];
-            if (errNorm > prevErr && ++lambdaLg10 <= 16) {
-                rc = accumulate(lambdaLg10);
-                if (rc) return rc;
-                continue;
-            }
-            break;
+            continue;
         }
         lambdaLg10 = std::max(lambdaLg10 - 1, -16);
         // relative parameter change ||p - p_prev|| / ||p_prev|| (extrinsics of all ranks, intrinsics once)
-        const double change = sqrt(hp[1] + hp[3]) / sqrt(hp[2] + hp[4]);
-        launch_calib_accept(s, c->stream);
-        HIPCHK(c, hipGetLastError());
+        const double change = sqrt(hp[1] + rep[0]) / sqrt(hp[2] + rep[1]);
+        calib_swap(s);
         if (++it >= max_iter || change < 2.220446049250313e-16) break;
         prevErr = errNorm;
+        if (lambdaLg10 != nextLg10) {  // (only when the damping had reached its ceiling)
+            rc = evaluate(0, lambdaLg10);
+            if (rc) return rc;
+        }
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     double out[12];

@@ -285,25 +285,24 @@ void launch_remap(const uint8_t* src, const uint2* map, uint8_t* dst, int B, int
 
 // calibration
 struct CalibState {
-    int V, P, NI;          // local views, points per view, active intrinsics (9 or 12)
-    const float* obj;      // [V,P,3]
-    const float* img;      // [V,P,2]
-    double* intr;          // [12] fx fy cx cy k1 k2 p1 p2 k3 k4 k5 k6 (current)
-    double* ext;           // [V,6] current
-    double* intrTrial;     // [12]
-    double* extTrial;      // [V,6]
-    double* viewBlocks;    // [V, 6*NI + 6] Aee'^-1 Bie^T and Aee'^-1 g_e saved by accumulate
-    double* partial;       // [V, NI*NI + NI + 1] per-view Schur records
-    double* acc;           // [NI*NI + NI + 1] reduced: S | rhs | err
-    double* errPartial;    // [V]
-    double* errOut;        // [1]
+    int V, P, NI;             // local views, points per view, active intrinsics (9 or 12)
+    const float* obj;         // [V,P,3]
+    const float* img;         // [V,P,2]
+    double* intr;             // [12] fx fy cx cy k1 k2 p1 p2 k3 k4 k5 k6 (current)
+    double* ext;              // [V,6] current
+    double* intrTrial;        // [12]
+    double* extTrial;         // [V,6]
+    double* viewBlocks;       // [V, 6*NI + 6] Aee'^-1 Bie^T and Aee'^-1 g_e of the current parameters
+    double* viewBlocksTrial;  // the same of the trial parameters (accepting a trial swaps the three pairs)
+    double* partial;          // [workgroups + 32, 160] per-workgroup records of k_calib_lm, then its per-group records
+    unsigned int* ticket;     // [1 + 32] groups done, workgroups done per group (k_calib_lm leaves them at 0)
 };
-void launch_calib_accumulate(const CalibState& s, double lambda, hipStream_t st);
-void launch_calib_backsub(const CalibState& s, const double* di, hipStream_t st);
-void launch_calib_error(const CalibState& s, int useTrial, hipStream_t st);
+// offsets into the CAMSYNC_CALIB_WORK_DOUBLES work buffer: the record [S | rhs | err | change sums] (summed over
+// ranks), the focal-length normal equations, the replicated values of a trial step, the intrinsic step
+constexpr int kWAcc = 0, kWFocal = 160, kWRec = 168, kWDelta = 176;
+int calib_lm_grid(int V);
+void launch_fill_i32(int32_t* dst, int n, int32_t value, hipStream_t st);
+void launch_calib_lm(const CalibState& s, int mode, double lambda, double* work, hipStream_t st);
 void launch_calib_focal_rows(const CalibState& s, double cx, double cy, double* rows, double* acc6, hipStream_t st);
-void launch_calib_accept(const CalibState& s, hipStream_t st);
-void launch_calib_solve(const CalibState& s, double* delta, double* flag, hipStream_t st);
-void launch_calib_change(const CalibState& s, double* rec, hipStream_t st);
 
 }  // namespace camsync

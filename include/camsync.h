@@ -258,14 +258,14 @@ int camsync_calibrate(camsync_ctx* ctx, const float* obj, const float* img, int 
                       double* rms, int32_t* iters);
 
 /* cv.calibrateCamera (camera.py:61-63) with the views sharded over ranks, one rank per GPU: this rank passes its
- * V_local views (may be 0) and the global count V_total; the Levenberg-Marquardt loop runs on the device and, per
- * iteration, sums two small records over the ranks through `allreduce`:
+ * V_local views (may be 0) and the global count V_total; the Levenberg-Marquardt loop runs on the device (one kernel per
+ * trial step) and sums one small record per trial step over the ranks through `allreduce`:
  *     int allreduce(void* user, double* d_buf, int n, void* hip_stream)
  * must replace d_buf[0..n) (DEVICE memory) by its sum over all ranks, ordered after the work already enqueued on
  * hip_stream (a hipStream_t) and before work enqueued on it later, and return 0 -- e.g.
  * ncclAllReduce(d_buf, d_buf, n, ncclDouble, ncclSum, comm, (hipStream_t)hip_stream) with RCCL, or
  * torch.distributed.all_reduce on a tensor aliasing the buffer (cameracalibration_amd/calibrate_dist.py).  n is 6
- * (focal initialisation), ni*ni + ni + 1 <= 157 (normal equations) or 3 (trial error and parameter change).  Every rank
+ * (focal initialisation) or ni*ni + ni + 3 <= 159 (normal equations, squared error, parameter change).  Every rank
  * makes the same sequence of calls.  d_work: optional caller-owned device buffer of CAMSYNC_CALIB_WORK_DOUBLES doubles
  * that then holds every record handed to `allreduce` (so a framework can register it once); NULL = the context's own.
  * allreduce == NULL is the single-GPU case (camsync_calibrate).  Outputs as camsync_calibrate; rvecs/tvecs are this
