@@ -305,7 +305,7 @@ def processArucoFromMultipleCameras(fixedArucos, movingArucos: dict, cameras, fr
     (_process_cameras_batched); the results are those of the loop."""
     assert len(cameras) == len(frame)
     fixedArucos = list(fixedArucos)
-    batchable = (0 < len(fixedArucos) <= 16 and len(cameras) > 0
+    batchable = (0 < len(fixedArucos) <= 64 and len(cameras) > 0
                  and all(getattr(c, "mtx", None) is not None and getattr(c, "dist", None) is not None for c in cameras))
     if batchable:
         results = _process_cameras_batched(fixedArucos, movingArucos.values(), cameras, frame, getMetrics)

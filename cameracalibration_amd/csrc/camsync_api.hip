@@ -375,6 +375,10 @@ int check_frame_args(camsync_ctx* c, const void* frames, int B, int H, int W, in
     return CAMSYNC_OK;
 }
 
+// Points per frame of the anchor PnP: 4 per visible anchor; 64 (one point per lane) covers the reference's sheets v1, v3
+// and v4, 128 / 256 (two / four per lane) a sheet of up to 32 / 64 anchors such as v2 (25 markers).
+static int anchor_points(int n_anchor) { return n_anchor <= 16 ? 64 : n_anchor <= 32 ? 128 : 256; }
+
 int ensure_pose_scratch(camsync_ctx* c, size_t B, int N) {
     if (B <= c->poseCap && N <= c->poseN) return CAMSYNC_OK;
     const size_t nB = std::max(B, c->poseCap);
@@ -633,8 +637,8 @@ static int detect_impl(camsync_ctx* c, const uint8_t* frames, const uint8_t* con
     if (c->dictN <= 0) return fail(c, CAMSYNC_E_ARG, "no dictionary set (camsync_set_dictionary)");
     if (max_markers < 1 || !ids || !corners || !counts) return fail(c, CAMSYNC_E_ARG, "detection outputs missing");
     if (withPose) {
-        if (n_anchor < 1 || n_anchor > 16 || !anchor_ids || !anchor_obj)
-            return fail(c, CAMSYNC_E_ARG, "1..16 anchors required (one wavefront lane per anchor corner)");
+        if (n_anchor < 1 || n_anchor > kMaxAnchors || !anchor_ids || !anchor_obj)
+            return fail(c, CAMSYNC_E_ARG, "1..64 anchors required");
         if (!K || ndist < 0 || ndist > 8 || (ndist > 0 && !dist)) return fail(c, CAMSYNC_E_ARG, "camera matrix / distortion missing");
         if (!rvec || !tvec || !pose_ok) return fail(c, CAMSYNC_E_ARG, "pose outputs missing");
     }
@@ -645,7 +649,7 @@ static int detect_impl(camsync_ctx* c, const uint8_t* frames, const uint8_t* con
     int32_t *const hIds = c->h_ids, *const hCounts = c->h_counts, *const hRejCounts = c->h_rejCounts;
     float *const hCorners = c->h_corners, *const hRej = c->h_rej;
     if (withPose) {
-        rc = ensure_pose_scratch(c, (size_t)c->maxB, 64);
+        rc = ensure_pose_scratch(c, (size_t)c->maxB, anchor_points(n_anchor));
         if (rc) return rc;
         HIPCHK(c, hipMemcpyAsync(c->d_anchorIds, anchor_ids, sizeof(int32_t) * n_anchor, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->d_anchorObj, anchor_obj, sizeof(float) * n_anchor * 12, hipMemcpyHostToDevice, c->stream));
@@ -677,9 +681,9 @@ static int detect_impl(camsync_ctx* c, const uint8_t* frames, const uint8_t* con
             HIPCHK(c, hipMemcpyAsync(c->d_K, K + kOff * 9, sizeof(double) * 9 * kCnt, hipMemcpyHostToDevice, c->stream));
             if (ndist) HIPCHK(c, hipMemcpyAsync(c->d_dist, dist + kOff * ndist, sizeof(double) * ndist * kCnt, hipMemcpyHostToDevice, c->stream));
             launch_gather_anchors(c->buf.outIds, c->buf.outCorners, c->buf.outCounts, nb, c->d_anchorIds, c->d_anchorObj,
-                                  n_anchor, c->d_obj, c->d_img, c->d_npts, c->stream);
+                                  n_anchor, anchor_points(n_anchor), c->d_obj, c->d_img, c->d_npts, c->stream);
             PnpArgs a{};
-            a.obj = c->d_obj; a.img = c->d_img; a.npts = c->d_npts; a.B = nb; a.N = 64;
+            a.obj = c->d_obj; a.img = c->d_img; a.npts = c->d_npts; a.B = nb; a.N = anchor_points(n_anchor);
             a.K = c->d_K; a.dist = c->d_dist; a.ndist = ndist; a.perFrameCam = per_frame_cam; a.refine = 1;
             a.rvec = c->d_rvec; a.tvec = c->d_tvec; a.ok = c->d_ok; a.mae = c->d_mae; a.rmse = c->d_rmse;
             launch_pnp(a, c->stream);
@@ -754,13 +758,13 @@ int camsync_detect_pnp_resident(camsync_ctx* c, const uint8_t* d_frames, int B, 
     int rc = check_frame_args(c, d_frames, B, H, W, C);
     if (rc) return rc;
     if (c->dictN <= 0) return fail(c, CAMSYNC_E_ARG, "no dictionary set (camsync_set_dictionary)");
-    if (n_anchor < 1 || n_anchor > 16 || !anchor_ids || !anchor_obj) return fail(c, CAMSYNC_E_ARG, "1..16 anchors required");
+    if (n_anchor < 1 || n_anchor > kMaxAnchors || !anchor_ids || !anchor_obj) return fail(c, CAMSYNC_E_ARG, "1..64 anchors required");
     if (!K || ndist < 0 || ndist > 8 || (ndist > 0 && !dist)) return fail(c, CAMSYNC_E_ARG, "camera matrix / distortion missing");
     if (max_markers < 1 || !d_ids || !d_corners || !d_counts || !d_rvec || !d_tvec || !d_pose_ok)
         return fail(c, CAMSYNC_E_ARG, "output pointers missing");
     if (((uintptr_t)d_frames) % 8) return fail(c, CAMSYNC_E_ARG, "device frames must be 8-byte aligned");
     HIPCHK(c, hipSetDevice(c->device));
-    rc = ensure_pose_scratch(c, (size_t)c->maxB, 64);
+    rc = ensure_pose_scratch(c, (size_t)c->maxB, anchor_points(n_anchor));
     if (rc) return rc;
     // anchors and camera are host pointers (small); frames and outputs live on the GPU
     HIPCHK(c, hipMemcpyAsync(c->d_anchorIds, anchor_ids, sizeof(int32_t) * n_anchor, hipMemcpyHostToDevice, c->stream));
@@ -774,9 +778,9 @@ int camsync_detect_pnp_resident(camsync_ctx* c, const uint8_t* d_frames, int B, 
         rc = enqueue_detect(c, d_frames + (size_t)b0 * px * C, nb, H, W, C);
         if (rc) return rc;
         launch_gather_anchors(c->buf.outIds, c->buf.outCorners, c->buf.outCounts, nb, c->d_anchorIds, c->d_anchorObj,
-                              n_anchor, c->d_obj, c->d_img, c->d_npts, c->stream);
+                              n_anchor, anchor_points(n_anchor), c->d_obj, c->d_img, c->d_npts, c->stream);
         PnpArgs a{};
-        a.obj = c->d_obj; a.img = c->d_img; a.npts = c->d_npts; a.B = nb; a.N = 64;
+        a.obj = c->d_obj; a.img = c->d_img; a.npts = c->d_npts; a.B = nb; a.N = anchor_points(n_anchor);
         a.K = c->d_K; a.dist = c->d_dist; a.ndist = ndist; a.perFrameCam = 0; a.refine = 1;
         a.rvec = d_rvec + (size_t)b0 * 3; a.tvec = d_tvec + (size_t)b0 * 3; a.ok = d_pose_ok + b0; a.mae = nullptr; a.rmse = nullptr;
         debug_stage(c->stream, "gather_anchors");
@@ -973,7 +977,7 @@ int camsync_pnp_batch(camsync_ctx* c, const float* obj, const float* img, const 
                       uint8_t* ok, double* mae, double* rmse) {
     if (!c) return CAMSYNC_E_ARG;
     if (!obj || !img || !npts || !K || !rvec || !tvec || !ok || B <= 0) return fail(c, CAMSYNC_E_ARG, "missing argument");
-    if (N < 4 || N > 64) return fail(c, CAMSYNC_E_ARG, "N must be 4..64 points per frame (one wavefront lane per point)");
+    if (N < 4 || N > 256) return fail(c, CAMSYNC_E_ARG, "N must be 4..256 points per frame");
     if (ndist < 0 || ndist > 8 || (ndist > 0 && !dist)) return fail(c, CAMSYNC_E_ARG, "ndist must be 0..8");
     HIPCHK(c, hipSetDevice(c->device));
     int rc = ensure_pose_scratch(c, (size_t)B, N);
@@ -1010,7 +1014,7 @@ int camsync_pnp_batch_noalloc(camsync_ctx* c, const float* obj, const float* img
                               double* tvec, uint8_t* ok, double* mae, double* rmse) {
     if (!c) return CAMSYNC_E_ARG;
     if (!obj || !img || !npts || !K || !rvec || !tvec || !ok || B <= 0) return fail(c, CAMSYNC_E_ARG, "missing argument");
-    if (N < 4 || N > 64) return fail(c, CAMSYNC_E_ARG, "N must be 4..64 points per frame (one wavefront lane per point)");
+    if (N < 4 || N > 256) return fail(c, CAMSYNC_E_ARG, "N must be 4..256 points per frame");
     if (ndist < 0 || ndist > 8 || (ndist > 0 && !dist)) return fail(c, CAMSYNC_E_ARG, "ndist must be 0..8");
     if ((size_t)B > kNaMaxFrames || (size_t)B * (size_t)N > kNaMaxPoints)
         return fail(c, CAMSYNC_E_CAPACITY,

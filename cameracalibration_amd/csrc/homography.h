@@ -1,5 +1,5 @@
-// homography.h — plane-to-image homography from n <= 64 correspondences, one
-// point per lane (cv.findHomography(method 0) as used inside solvePnP's planar
+// homography.h — plane-to-image homography from n <= 64 PPL correspondences, PPL
+// points per lane (cv.findHomography(method 0) as used inside solvePnP's planar
 // initialisation and calibrateCamera's focal-length initialisation): data
 // normalisation as in runKernel, linear solve of the normalised system, then a
 // Gauss-Newton polish of the reprojection error.  All lanes return the same H
@@ -10,29 +10,62 @@
 
 namespace camsync {
 
-__device__ __forceinline__ bool wave_homography(double Mx, double My, double xn, double yn, bool active, int n, double* H) {
+// Sum over a lane's PPL points of f(k), the first term taken as it is (so that one point per lane adds nothing).
+template <int PPL, typename F>
+__device__ __forceinline__ double lane_sum(F f) {
+    double t = f(0);
+#pragma unroll
+    for (int k = 1; k < PPL; k++) t += f(k);
+    return t;
+}
+
+// Point i of the set is held by lane i % 64 as its point i / 64.
+template <int PPL>
+__device__ __forceinline__ bool wave_homography(const double (&Mx_)[PPL], const double (&My_)[PPL], const double (&xn_)[PPL],
+                                                const double (&yn_)[PPL], const bool (&active)[PPL], int n, double* H) {
     const double invn = 1.0 / n;
-    if (!active) { Mx = 0; My = 0; xn = 0; yn = 0; }
+    double Mx[PPL], My[PPL], xn[PPL], yn[PPL], w0[PPL];
+#pragma unroll
+    for (int k = 0; k < PPL; k++) {
+        Mx[k] = active[k] ? Mx_[k] : 0; My[k] = active[k] ? My_[k] : 0;
+        xn[k] = active[k] ? xn_[k] : 0; yn[k] = active[k] ? yn_[k] : 0;
+        w0[k] = active[k] ? 1.0 : 0.0;
+    }
     // normalisation of both point sets (findHomography's runKernel)
-    const double cMx = wsum(Mx) * invn, cMy = wsum(My) * invn, cmx = wsum(xn) * invn, cmy = wsum(yn) * invn;
-    double sMx = wsum(active ? fabs(Mx - cMx) : 0), sMy = wsum(active ? fabs(My - cMy) : 0);
-    double smx = wsum(active ? fabs(xn - cmx) : 0), smy = wsum(active ? fabs(yn - cmy) : 0);
+    const double cMx = wsum(lane_sum<PPL>([&](int k) { return Mx[k]; })) * invn, cMy = wsum(lane_sum<PPL>([&](int k) { return My[k]; })) * invn;
+    const double cmx = wsum(lane_sum<PPL>([&](int k) { return xn[k]; })) * invn, cmy = wsum(lane_sum<PPL>([&](int k) { return yn[k]; })) * invn;
+    double sMx = wsum(lane_sum<PPL>([&](int k) { return active[k] ? fabs(Mx[k] - cMx) : 0; }));
+    double sMy = wsum(lane_sum<PPL>([&](int k) { return active[k] ? fabs(My[k] - cMy) : 0; }));
+    double smx = wsum(lane_sum<PPL>([&](int k) { return active[k] ? fabs(xn[k] - cmx) : 0; }));
+    double smy = wsum(lane_sum<PPL>([&](int k) { return active[k] ? fabs(yn[k] - cmy) : 0; }));
     const double tiny = 2.220446049250313e-16;
     bool hok = !(fabs(sMx) < tiny || fabs(sMy) < tiny || fabs(smx) < tiny || fabs(smy) < tiny);
     if (hok) {
         sMx = n / sMx; sMy = n / sMy; smx = n / smx; smy = n / smy;
-        const double xx = (xn - cmx) * smx, yy = (yn - cmy) * smy;
-        const double XX = (Mx - cMx) * sMx, YY = (My - cMy) * sMy;
-        const double w0 = active ? 1.0 : 0.0;
-        const double r0[8] = {XX * w0, YY * w0, w0, 0, 0, 0, -xx * XX * w0, -xx * YY * w0};
-        const double r1[8] = {0, 0, 0, XX * w0, YY * w0, w0, -yy * XX * w0, -yy * YY * w0};
         double A[64], b[8];
 #pragma unroll
+        for (int k = 0; k < PPL; k++) {
+            const double xx = (xn[k] - cmx) * smx, yy = (yn[k] - cmy) * smy;
+            const double XX = (Mx[k] - cMx) * sMx, YY = (My[k] - cMy) * sMy;
+            const double r0[8] = {XX * w0[k], YY * w0[k], w0[k], 0, 0, 0, -xx * XX * w0[k], -xx * YY * w0[k]};
+            const double r1[8] = {0, 0, 0, XX * w0[k], YY * w0[k], w0[k], -yy * XX * w0[k], -yy * YY * w0[k]};
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const double t = r0[i] * xx + r1[i] * yy;
+                b[i] = k == 0 ? t : b[i] + t;
+#pragma unroll
+                for (int j = i; j < 8; j++) {
+                    const double s = r0[i] * r0[j] + r1[i] * r1[j];
+                    A[i * 8 + j] = k == 0 ? s : A[i * 8 + j] + s;
+                }
+            }
+        }
+#pragma unroll
         for (int i = 0; i < 8; i++) {
-            b[i] = wsum(r0[i] * xx + r1[i] * yy);
+            b[i] = wsum(b[i]);
 #pragma unroll
             for (int j = i; j < 8; j++) {
-                const double s = wsum(r0[i] * r0[j] + r1[i] * r1[j]);
+                const double s = wsum(A[i * 8 + j]);
                 A[i * 8 + j] = s;
                 A[j * 8 + i] = s;
             }
@@ -55,24 +88,38 @@ __device__ __forceinline__ bool wave_homography(double Mx, double My, double xn,
         double cur = -1;
 #pragma unroll 1
         for (int it = 0; it < 6; it++) {
-            double ww = H[6] * Mx + H[7] * My + 1.;
-            ww = fabs(ww) > tiny ? 1. / ww : 0;
-            const double xi = (H[0] * Mx + H[1] * My + H[2]) * ww, yi = (H[3] * Mx + H[4] * My + H[5]) * ww;
-            const double w0 = active ? 1.0 : 0.0;
-            const double ex = (xi - xn) * w0, ey = (yi - yn) * w0;
-            const double cost = wsum(ex * ex + ey * ey);
+            double A[64], b[8], cost = 0;
+#pragma unroll
+            for (int k = 0; k < PPL; k++) {
+                double ww = H[6] * Mx[k] + H[7] * My[k] + 1.;
+                ww = fabs(ww) > tiny ? 1. / ww : 0;
+                const double xi = (H[0] * Mx[k] + H[1] * My[k] + H[2]) * ww, yi = (H[3] * Mx[k] + H[4] * My[k] + H[5]) * ww;
+                const double ex = (xi - xn[k]) * w0[k], ey = (yi - yn[k]) * w0[k];
+                const double c = ex * ex + ey * ey;
+                cost = k == 0 ? c : cost + c;
+                const double jx[8] = {Mx[k] * ww * w0[k], My[k] * ww * w0[k], ww * w0[k], 0, 0, 0, -Mx[k] * ww * xi * w0[k], -My[k] * ww * xi * w0[k]};
+                const double jy[8] = {0, 0, 0, Mx[k] * ww * w0[k], My[k] * ww * w0[k], ww * w0[k], -Mx[k] * ww * yi * w0[k], -My[k] * ww * yi * w0[k]};
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const double t = jx[i] * ex + jy[i] * ey;
+                    b[i] = k == 0 ? t : b[i] + t;
+#pragma unroll
+                    for (int j = i; j < 8; j++) {
+                        const double s = jx[i] * jx[j] + jy[i] * jy[j];
+                        A[i * 8 + j] = k == 0 ? s : A[i * 8 + j] + s;
+                    }
+                }
+            }
+            cost = wsum(cost);
             if (cur >= 0 && !(cost < cur)) break;
             cur = cost;
-            const double jx[8] = {Mx * ww * w0, My * ww * w0, ww * w0, 0, 0, 0, -Mx * ww * xi * w0, -My * ww * xi * w0};
-            const double jy[8] = {0, 0, 0, Mx * ww * w0, My * ww * w0, ww * w0, -Mx * ww * yi * w0, -My * ww * yi * w0};
-            double A[64], b[8];
             double tr = 0;
 #pragma unroll
             for (int i = 0; i < 8; i++) {
-                b[i] = wsum(jx[i] * ex + jy[i] * ey);
+                b[i] = wsum(b[i]);
 #pragma unroll
                 for (int j = i; j < 8; j++) {
-                    const double s = wsum(jx[i] * jx[j] + jy[i] * jy[j]);
+                    const double s = wsum(A[i * 8 + j]);
                     A[i * 8 + j] = s;
                     A[j * 8 + i] = s;
                 }
@@ -86,16 +133,25 @@ __device__ __forceinline__ bool wave_homography(double Mx, double My, double xn,
 #pragma unroll
             for (int i = 0; i < 8; i++) Hs[i] = H[i] - b[i];
             // accept only if the cost does not grow
-            double w2 = Hs[6] * Mx + Hs[7] * My + 1.;
-            w2 = fabs(w2) > tiny ? 1. / w2 : 0;
-            const double x2 = (Hs[0] * Mx + Hs[1] * My + Hs[2]) * w2, y2 = (Hs[3] * Mx + Hs[4] * My + Hs[5]) * w2;
-            const double c2 = wsum(((x2 - xn) * (x2 - xn) + (y2 - yn) * (y2 - yn)) * w0);
+            const double c2 = wsum(lane_sum<PPL>([&](int k) {
+                double w2 = Hs[6] * Mx[k] + Hs[7] * My[k] + 1.;
+                w2 = fabs(w2) > tiny ? 1. / w2 : 0;
+                const double x2 = (Hs[0] * Mx[k] + Hs[1] * My[k] + Hs[2]) * w2, y2 = (Hs[3] * Mx[k] + Hs[4] * My[k] + Hs[5]) * w2;
+                return ((x2 - xn[k]) * (x2 - xn[k]) + (y2 - yn[k]) * (y2 - yn[k])) * w0[k];
+            }));
             if (!(c2 <= cost)) break;
 #pragma unroll
             for (int i = 0; i < 8; i++) H[i] = Hs[i];
         }
     }
     return hok;
+}
+
+// one point per lane
+__device__ __forceinline__ bool wave_homography(double Mx, double My, double xn, double yn, bool active, int n, double* H) {
+    const double a[1] = {Mx}, b[1] = {My}, c[1] = {xn}, d[1] = {yn};
+    const bool act[1] = {active};
+    return wave_homography<1>(a, b, c, d, act, n, H);
 }
 
 }  // namespace camsync

@@ -265,7 +265,7 @@ struct PnpArgs {
 };
 void launch_pnp(const PnpArgs& a, hipStream_t st);
 void launch_gather_anchors(const int32_t* ids, const float* corners, const int32_t* counts, int B,
-                           const int32_t* anchorIds, const float* anchorObj, int nAnchor,
+                           const int32_t* anchorIds, const float* anchorObj, int nAnchor, int N,
                            float* obj, float* img, int32_t* npts, hipStream_t st);
 void launch_ippe(const float* corners, const double* size, int B, const double* K, const double* dist,
                  int ndist, int perFrameCam, double* rvec, double* tvec, uint8_t* ok, hipStream_t st);

@@ -83,39 +83,58 @@ struct PoseSums {
 };
 
 // Residuals (and optionally the normal equations) of the pixel reprojection
-// error at pose p, one point per lane.
-template <bool WITH_J>
-__device__ __forceinline__ void pose_eval(const Cam& cam, const double* p, bool active, double X, double Y, double Z,
-                                          double ui, double vi, PoseSums& S) {
+// error at pose p, PPL points per lane.
+template <bool WITH_J, int PPL>
+__device__ __forceinline__ void pose_eval(const Cam& cam, const double* p, const bool (&active)[PPL], const double (&X)[PPL],
+                                          const double (&Y)[PPL], const double (&Z)[PPL], const double (&ui)[PPL],
+                                          const double (&vi)[PPL], PoseSums& S) {
     double R[9], dR[27];
     rodrigues_v2m(p, R, WITH_J ? dR : nullptr);
-    const double Xc = R[0] * X + R[1] * Y + R[2] * Z + p[3];
-    const double Yc = R[3] * X + R[4] * Y + R[5] * Z + p[4];
-    const double Zc = R[6] * X + R[7] * Y + R[8] * Z + p[5];
-    double u, v, duP[3], dvP[3];
-    project_cam<WITH_J, false>(cam, Xc, Yc, Zc, u, v, duP, dvP, nullptr, nullptr);
-    const double ex = active ? u - ui : 0.0, ey = active ? v - vi : 0.0;
-    S.err2 = wsum(ex * ex + ey * ey);
-    double m = fmax(fabs(ex), fabs(ey));
-    m = wave_allreduce(m, [](double a, double b) { return fmax(a, b); });
-    S.rinf = m;
-    if (WITH_J) {
-        double ju[6], jv[6];
+    double e2 = 0, m = 0, jte[6], jtj[36];
 #pragma unroll
-        for (int q = 0; q < 3; q++) {
-            const double* D = dR + q * 9;
-            const double dP0 = D[0] * X + D[1] * Y + D[2] * Z, dP1 = D[3] * X + D[4] * Y + D[5] * Z, dP2 = D[6] * X + D[7] * Y + D[8] * Z;
-            ju[q] = active ? duP[0] * dP0 + duP[1] * dP1 + duP[2] * dP2 : 0.0;
-            jv[q] = active ? dvP[0] * dP0 + dvP[1] * dP1 + dvP[2] * dP2 : 0.0;
-            ju[3 + q] = active ? duP[q] : 0.0;
-            jv[3 + q] = active ? dvP[q] : 0.0;
+    for (int k = 0; k < PPL; k++) {
+        const double Xc = R[0] * X[k] + R[1] * Y[k] + R[2] * Z[k] + p[3];
+        const double Yc = R[3] * X[k] + R[4] * Y[k] + R[5] * Z[k] + p[4];
+        const double Zc = R[6] * X[k] + R[7] * Y[k] + R[8] * Z[k] + p[5];
+        double u, v, duP[3], dvP[3];
+        project_cam<WITH_J, false>(cam, Xc, Yc, Zc, u, v, duP, dvP, nullptr, nullptr);
+        const double ex = active[k] ? u - ui[k] : 0.0, ey = active[k] ? v - vi[k] : 0.0;
+        const double ek = ex * ex + ey * ey, mk = fmax(fabs(ex), fabs(ey));
+        e2 = k == 0 ? ek : e2 + ek;
+        m = k == 0 ? mk : fmax(m, mk);
+        if (WITH_J) {
+            double ju[6], jv[6];
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                const double* D = dR + q * 9;
+                const double dP0 = D[0] * X[k] + D[1] * Y[k] + D[2] * Z[k], dP1 = D[3] * X[k] + D[4] * Y[k] + D[5] * Z[k],
+                             dP2 = D[6] * X[k] + D[7] * Y[k] + D[8] * Z[k];
+                ju[q] = active[k] ? duP[0] * dP0 + duP[1] * dP1 + duP[2] * dP2 : 0.0;
+                jv[q] = active[k] ? dvP[0] * dP0 + dvP[1] * dP1 + dvP[2] * dP2 : 0.0;
+                ju[3 + q] = active[k] ? duP[q] : 0.0;
+                jv[3 + q] = active[k] ? dvP[q] : 0.0;
+            }
+#pragma unroll
+            for (int a = 0; a < 6; a++) {
+                const double t = ju[a] * ex + jv[a] * ey;
+                jte[a] = k == 0 ? t : jte[a] + t;
+#pragma unroll
+                for (int b = a; b < 6; b++) {
+                    const double s = ju[a] * ju[b] + jv[a] * jv[b];
+                    jtj[a * 6 + b] = k == 0 ? s : jtj[a * 6 + b] + s;
+                }
+            }
         }
+    }
+    S.err2 = wsum(e2);
+    S.rinf = wave_allreduce(m, [](double a, double b) { return fmax(a, b); });
+    if (WITH_J) {
 #pragma unroll
         for (int a = 0; a < 6; a++) {
-            S.Jte[a] = wsum(ju[a] * ex + jv[a] * ey);
+            S.Jte[a] = wsum(jte[a]);
 #pragma unroll
             for (int b = a; b < 6; b++) {
-                const double s = wsum(ju[a] * ju[b] + jv[a] * jv[b]);
+                const double s = wsum(jtj[a * 6 + b]);
                 S.JtJ[a * 6 + b] = s;
                 S.JtJ[b * 6 + a] = s;
             }
@@ -151,33 +170,51 @@ __device__ __forceinline__ bool damped_solve(const PoseSums& S, double lambda, b
     return ok;
 }
 
+// Point i of a frame is held by lane i % 64 as its point i / 64 (PPL points per lane: up to 64 PPL points).
+template <int PPL>
 __global__ __launch_bounds__(64) void k_pnp(PnpArgs a) {
     const int lane = threadIdx.x;
     for (int f = blockIdx.x; f < a.B; f += gridDim.x) {
-        const int n = min(a.npts[f], min(a.N, 64));
-        const bool active = lane < n;
+        const int n = min(a.npts[f], min(a.N, 64 * PPL));
         const Cam cam = load_cam(a.K + (a.perFrameCam ? (size_t)f * 9 : 0), a.dist + (a.perFrameCam ? (size_t)f * a.ndist : 0), a.ndist);
-        double X = 0, Y = 0, Z = 0, ui = 0, vi = 0;
-        if (active) {
-            const float* o = a.obj + ((size_t)f * a.N + lane) * 3;
-            const float* m = a.img + ((size_t)f * a.N + lane) * 2;
-            X = o[0]; Y = o[1]; Z = o[2];
-            ui = m[0]; vi = m[1];
+        bool active[PPL];
+        double X[PPL], Y[PPL], Z[PPL], ui[PPL], vi[PPL];
+#pragma unroll
+        for (int k = 0; k < PPL; k++) {
+            const int i = k * 64 + lane;
+            active[k] = i < n;
+            X[k] = Y[k] = Z[k] = ui[k] = vi[k] = 0;
+            if (active[k]) {
+                const float* o = a.obj + ((size_t)f * a.N + i) * 3;
+                const float* m = a.img + ((size_t)f * a.N + i) * 2;
+                X[k] = o[0]; Y[k] = o[1]; Z[k] = o[2];
+                ui[k] = m[0]; vi[k] = m[1];
+            }
         }
         int status = 1;
         double p[6] = {0, 0, 0, 0, 0, 0};
         if (n < 4) status = 0;
         if (status == 1) {
             // ---- initial pose (cvFindExtrinsicCameraParams2) ----
-            double xn = 0, yn = 0;
-            undistort_point(cam, ui, vi, xn, yn);
-            if (!active) { xn = 0; yn = 0; }
+            double xn[PPL], yn[PPL];
+#pragma unroll
+            for (int k = 0; k < PPL; k++) {
+                xn[k] = yn[k] = 0;
+                undistort_point(cam, ui[k], vi[k], xn[k], yn[k]);
+                if (!active[k]) { xn[k] = 0; yn[k] = 0; }
+            }
             const double invn = 1.0 / n;
-            const double Mc[3] = {wsum(X) * invn, wsum(Y) * invn, wsum(Z) * invn};
-            const double d0 = active ? X - Mc[0] : 0, d1 = active ? Y - Mc[1] : 0, d2 = active ? Z - Mc[2] : 0;
+            const double Mc[3] = {wsum(lane_sum<PPL>([&](int k) { return X[k]; })) * invn, wsum(lane_sum<PPL>([&](int k) { return Y[k]; })) * invn,
+                                  wsum(lane_sum<PPL>([&](int k) { return Z[k]; })) * invn};
+            double d0[PPL], d1[PPL], d2[PPL];
+#pragma unroll
+            for (int k = 0; k < PPL; k++) {
+                d0[k] = active[k] ? X[k] - Mc[0] : 0; d1[k] = active[k] ? Y[k] - Mc[1] : 0; d2[k] = active[k] ? Z[k] - Mc[2] : 0;
+            }
             double MM[9];
-            MM[0] = wsum(d0 * d0); MM[1] = wsum(d0 * d1); MM[2] = wsum(d0 * d2);
-            MM[4] = wsum(d1 * d1); MM[5] = wsum(d1 * d2); MM[8] = wsum(d2 * d2);
+            MM[0] = wsum(lane_sum<PPL>([&](int k) { return d0[k] * d0[k]; })); MM[1] = wsum(lane_sum<PPL>([&](int k) { return d0[k] * d1[k]; }));
+            MM[2] = wsum(lane_sum<PPL>([&](int k) { return d0[k] * d2[k]; })); MM[4] = wsum(lane_sum<PPL>([&](int k) { return d1[k] * d1[k]; }));
+            MM[5] = wsum(lane_sum<PPL>([&](int k) { return d1[k] * d2[k]; })); MM[8] = wsum(lane_sum<PPL>([&](int k) { return d2[k] * d2[k]; }));
             MM[3] = MM[1]; MM[6] = MM[2]; MM[7] = MM[5];
             double Wv[3], V[9];
             eigen3(MM, Wv, V);
@@ -198,10 +235,14 @@ __global__ __launch_bounds__(64) void k_pnp(PnpArgs a) {
                 double tt[3];
 #pragma unroll
                 for (int q = 0; q < 3; q++) tt[q] = -(Rt[q * 3] * Mc[0] + Rt[q * 3 + 1] * Mc[1] + Rt[q * 3 + 2] * Mc[2]);
-                const double Mx = active ? Rt[0] * X + Rt[1] * Y + Rt[2] * Z + tt[0] : 0;
-                const double My = active ? Rt[3] * X + Rt[4] * Y + Rt[5] * Z + tt[1] : 0;
+                double Mx[PPL], My[PPL];
+#pragma unroll
+                for (int k = 0; k < PPL; k++) {
+                    Mx[k] = active[k] ? Rt[0] * X[k] + Rt[1] * Y[k] + Rt[2] * Z[k] + tt[0] : 0;
+                    My[k] = active[k] ? Rt[3] * X[k] + Rt[4] * Y[k] + Rt[5] * Z[k] + tt[1] : 0;
+                }
                 double H[9];
-                const bool hok = wave_homography(Mx, My, xn, yn, active, n, H);
+                const bool hok = wave_homography<PPL>(Mx, My, xn, yn, active, n, H);
                 double R[9], t[3];
                 bool fin = hok;
 #pragma unroll
@@ -241,7 +282,7 @@ __global__ __launch_bounds__(64) void k_pnp(PnpArgs a) {
                 double prev[6], step[6];
 #pragma unroll 1
                 for (;;) {
-                    pose_eval<true>(cam, p, active, X, Y, Z, ui, vi, S);
+                    pose_eval<true, PPL>(cam, p, active, X, Y, Z, ui, vi, S);
 #pragma unroll
                     for (int i = 0; i < 6; i++) prev[i] = p[i];
                     if (iters == 0) prevErr = sqrt(S.err2);
@@ -251,7 +292,7 @@ __global__ __launch_bounds__(64) void k_pnp(PnpArgs a) {
 #pragma unroll 1
                     for (;;) {
                         PoseSums E;
-                        pose_eval<false>(cam, p, active, X, Y, Z, ui, vi, E);
+                        pose_eval<false, PPL>(cam, p, active, X, Y, Z, ui, vi, E);
                         errNorm = sqrt(E.err2);
                         if (errNorm > prevErr && ++lambdaLg10 <= 16) {
                             damped_solve(S, exp(lambdaLg10 * 2.302585092994046), true, nullptr, step);
@@ -273,7 +314,7 @@ __global__ __launch_bounds__(64) void k_pnp(PnpArgs a) {
             // ---- phase 2: solvePnPRefineLM = LMSolver(20, FLT_EPSILON) ----
             if (a.refine) {
                 const double eps = 1.1920928955078125e-07;
-                pose_eval<true>(cam, p, active, X, Y, Z, ui, vi, S);
+                pose_eval<true, PPL>(cam, p, active, X, Y, Z, ui, vi, S);
                 double Sc = S.err2, rinf = S.rinf;
                 double D[6];
 #pragma unroll
@@ -288,7 +329,7 @@ __global__ __launch_bounds__(64) void k_pnp(PnpArgs a) {
 #pragma unroll
                     for (int i = 0; i < 6; i++) xd[i] = p[i] - d[i];
                     PoseSums E;
-                    pose_eval<false>(cam, xd, active, X, Y, Z, ui, vi, E);
+                    pose_eval<false, PPL>(cam, xd, active, X, Y, Z, ui, vi, E);
                     const double Sd = E.err2;
                     double dS = 0, tdv = 0;
 #pragma unroll
@@ -334,7 +375,7 @@ __global__ __launch_bounds__(64) void k_pnp(PnpArgs a) {
                         Sc = Sd;
 #pragma unroll
                         for (int i = 0; i < 6; i++) p[i] = xd[i];
-                        pose_eval<true>(cam, p, active, X, Y, Z, ui, vi, S);
+                        pose_eval<true, PPL>(cam, p, active, X, Y, Z, ui, vi, S);
                         rinf = S.rinf;
                     }
                     iter++;
@@ -350,13 +391,17 @@ __global__ __launch_bounds__(64) void k_pnp(PnpArgs a) {
         if (status == 1) {
             double R[9];
             rodrigues_v2m(p, R, nullptr);
-            const double Xc = R[0] * X + R[1] * Y + R[2] * Z + p[3];
-            const double Yc = R[3] * X + R[4] * Y + R[5] * Z + p[4];
-            const double Zc = R[6] * X + R[7] * Y + R[8] * Z + p[5];
-            double u, v;
-            project_cam<false, false>(cam, Xc, Yc, Zc, u, v, nullptr, nullptr, nullptr, nullptr);
-            const double dist2 = active ? (u - ui) * (u - ui) + (v - vi) * (v - vi) : 0.0;
-            const double sd = wsum(sqrt(dist2)), sd2 = wsum(dist2);
+            double dist2[PPL];
+#pragma unroll
+            for (int k = 0; k < PPL; k++) {
+                const double Xc = R[0] * X[k] + R[1] * Y[k] + R[2] * Z[k] + p[3];
+                const double Yc = R[3] * X[k] + R[4] * Y[k] + R[5] * Z[k] + p[4];
+                const double Zc = R[6] * X[k] + R[7] * Y[k] + R[8] * Z[k] + p[5];
+                double u, v;
+                project_cam<false, false>(cam, Xc, Yc, Zc, u, v, nullptr, nullptr, nullptr, nullptr);
+                dist2[k] = active[k] ? (u - ui[k]) * (u - ui[k]) + (v - vi[k]) * (v - vi[k]) : 0.0;
+            }
+            const double sd = wsum(lane_sum<PPL>([&](int k) { return sqrt(dist2[k]); })), sd2 = wsum(lane_sum<PPL>([&](int k) { return dist2[k]; }));
             if (lane == 0) {
                 for (int i = 0; i < 3; i++) { a.rvec[(size_t)f * 3 + i] = p[i]; a.tvec[(size_t)f * 3 + i] = p[3 + i]; }
                 if (a.ok) a.ok[f] = 1;
@@ -514,15 +559,18 @@ __global__ void k_ippe(const float* __restrict__ corners, const double* __restri
 
 void launch_pnp(const PnpArgs& a, hipStream_t st) {
     if (a.B <= 0) return;
-    hipLaunchKernelGGL(k_pnp, dim3(min(a.B, 256 * 16)), dim3(64), 0, st, a);
+    const dim3 grid(min(a.B, 256 * 16));
+    if (a.N <= 64) hipLaunchKernelGGL(k_pnp<1>, grid, dim3(64), 0, st, a);
+    else if (a.N <= 128) hipLaunchKernelGGL(k_pnp<2>, grid, dim3(64), 0, st, a);
+    else hipLaunchKernelGGL(k_pnp<4>, grid, dim3(64), 0, st, a);
 }
 
 void launch_gather_anchors(const int32_t* ids, const float* corners, const int32_t* counts, int B,
-                           const int32_t* anchorIds, const float* anchorObj, int nAnchor, float* obj, float* img,
-                           int32_t* npts, hipStream_t st) {
+                           const int32_t* anchorIds, const float* anchorObj, int nAnchor, int N, float* obj,
+                           float* img, int32_t* npts, hipStream_t st) {
     if (B <= 0) return;
     hipLaunchKernelGGL(k_gather_anchors, dim3((B + 63) / 64), dim3(64), 0, st, ids, corners, counts, B, kMaxMarkerOut,
-                       anchorIds, anchorObj, nAnchor, 4 * kMaxAnchors > 64 ? 64 : 4 * kMaxAnchors, obj, img, npts);
+                       anchorIds, anchorObj, nAnchor, N, obj, img, npts);
 }
 
 void launch_ippe(const float* corners, const double* size, int B, const double* K, const double* dist, int ndist,

@@ -151,7 +151,8 @@ int camsync_debug_restore_capacity(camsync_ctx* ctx);
 
 /* cv.solvePnP(ITERATIVE) followed by cv.solvePnPRefineLM, batched
  * (aruco.py:368-384), plus the MAE/RMSE of aruco.py:386-400.
- * obj f32 [B,N,3], img f32 [B,N,2], npts i32 [B] (<= N), K f64 [B or 1,3,3],
+ * obj f32 [B,N,3], img f32 [B,N,2] (4 <= N <= 256: a wavefront per frame, up to
+ * four points per lane), npts i32 [B] (<= N), K f64 [B or 1,3,3],
  * dist f64 [B or 1, ndist] (ndist <= 8: k1,k2,p1,p2,k3,k4,k5,k6),
  * per_frame_cam: 1 if K/dist are per frame.  Outputs (host): rvec,tvec f64
  * [B,3], ok u8 [B], mae,rmse f64 [B] (may be NULL). */
@@ -183,7 +184,7 @@ int camsync_ippe_square_batch(camsync_ctx* ctx, const float* corners, const doub
 
 /* detectAruco + anchor gather + PnP fused on device: the body of processAruco
  * up to camera.updateWorldPosition (aruco.py:305-336) for B frames.
- * anchors: n_anchor ids with their 4 object corners f32 [n_anchor,4,3]
+ * anchors: n_anchor <= 64 ids with their 4 object corners f32 [n_anchor,4,3]
  * (Aruco.getCornersAsList order, aruco.py:58-67).  Frames that see < 1 anchor
  * (fewer than 4 points) get pose_ok = 0 (processAruco returns False / raises).
  * Detection outputs as camsync_detect_batch. */

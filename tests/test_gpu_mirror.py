@@ -263,6 +263,48 @@ def _nccl_rank_main(rank, world, port, V, out_dir):
         dist.destroy_process_group()
 
 
+def test_v2_sheet_as_anchors_batched_equals_the_per_camera_loop():
+    """The reference's v2 sheet (aruco.py:140-150: 25 markers) as fixedArucos is 23 anchors = 92 points with two of
+    them moving: more than one point per lane in the PnP kernels, in the fused batch and in the mirror's PnP."""
+    import copy
+    from cameracalibration_amd import synth
+    from cameracalibration_amd.camera_sync.aruco import (Aruco, getArucosFromPaper, processAruco,
+                                                         processArucoFromMultipleCameras)
+    from cameracalibration_amd.camera_sync.camera import Camera
+
+    sheet = getArucosFromPaper(2)
+    layout = [(a.id, float(a.corners[0].coords[0]), float(a.corners[0].coords[1]), float(a.size)) for a in sheet.values()]
+    cx = np.mean([m[1] + m[3] / 2 for m in layout])
+    cy = np.mean([m[2] - m[3] / 2 for m in layout])
+    frames, cams = [], []
+    for i in range(3):
+        cam = Camera("Logitec_robot", -1, focus=10, resolution=(1920, 1080))
+        rng = np.random.default_rng(900 + i)
+        R, t = synth.look_at_pose(rng, (cx, cy), dist_range=(300.0, 420.0), tilt_range=(0.0, 35.0))
+        frames.append(synth.render_sheet(layout, cam.mtx, R, t, 1080, 1920, seed=900 + i, ss=2, device="cuda").cpu().numpy())
+        cams.append(cam)
+    ids = sorted(sheet)
+    fixed = [sheet[i] for i in ids[:-2]]
+    assert len(fixed) == 23
+
+    def run(batched):
+        cs = copy.deepcopy(cams)
+        moving = {k: copy.deepcopy(sheet[k]) for k in ids[-2:]}
+        if batched:
+            processArucoFromMultipleCameras(fixed, moving, cs, frames, getMetrics=True)
+        else:
+            for cam, f in zip(cs, frames):
+                res = processAruco(fixed, moving.values(), cam, f, accept_none=True, directUpdate=False, metrics=True)
+                assert res, "the camera must see the sheet"
+        return cs
+
+    cb, cl = run(True), run(False)
+    for a, b in zip(cb, cl):
+        assert hasattr(a, "world2cam") and hasattr(b, "world2cam")
+        assert np.allclose(a.world2cam.transf_mat, b.world2cam.transf_mat, rtol=1e-9, atol=1e-9)
+        assert np.allclose(a.world_position.coords, b.world_position.coords, rtol=1e-9, atol=1e-9)
+
+
 def test_distributed_calibration_over_rccl_world_1(tmp_path):
     """The RCCL leg of the distributed calibration (process group backend "nccl"), as far as one GPU can run it:
     a one-rank group, every record of every LM iteration all-reduced by RCCL on the device buffer.  The result must be

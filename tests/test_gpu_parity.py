@@ -233,6 +233,42 @@ def test_pnp_batch_random_poses_vs_oracle(ctx):
         assert np.allclose(tvec[b], otv, rtol=1e-6, atol=1e-6), (b, tvec[b], otv)
 
 
+@pytest.mark.parametrize("n_markers", [25, 50])
+def test_pnp_more_than_64_points_vs_oracle(ctx, n_markers):
+    """cv.solvePnP has no point limit (aruco.py:368): the reference's v2 sheet as anchors is 25 markers = 100 points
+    (two points per lane), the whole dictionary 50 markers = 200 points (four per lane)."""
+    from cameracalibration_amd import synth
+    from cameracalibration_amd.camera_sync.aruco import getArucosFromPaper
+    K, dist = _data.calibration("Logitec_robot_1920-1080_10.npz")
+    rng = np.random.default_rng(23)
+    sheet = list(getArucosFromPaper(2).values())
+    pts = np.array([a.getCornersAsList() for a in sheet], np.float32).reshape(-1, 3)   # 100 points of the v2 sheet
+    if n_markers == 50:
+        pts = np.concatenate([pts, pts + np.float32([200.0, 0.0, 0.0])])               # a second sheet beside it
+    N = len(pts)
+    assert N == 4 * n_markers
+    B = 12
+    obj = np.broadcast_to(pts.reshape(1, N, 3), (B, N, 3)).copy()
+    img = np.zeros((B, N, 2), np.float32)
+    centre = tuple(pts[:, :2].mean(axis=0))
+    for b in range(B):
+        R, t = synth.look_at_pose(rng, centre)
+        rv = orc.rodrigues_mat2vec(R)
+        img[b] = (orc.project_points(obj[b], rv, t, K, dist) + rng.normal(0, 0.3, (N, 2))).astype(np.float32)
+    npts = np.full(B, N, np.int32)
+    npts[3] = 68   # ragged: a little more than one point per lane
+    npts[4] = 64
+    rvec, tvec, ok, mae, rmse = ctx.pnp(obj, img, npts, K, dist)
+    for b in range(B):
+        o_ok, orv, otv = orc.solve_pnp(obj[b, :npts[b]], img[b, :npts[b]], K, dist)
+        assert ok[b] == 1 and o_ok
+        assert np.allclose(rvec[b], orv, rtol=1e-6, atol=1e-8), (b, rvec[b], orv)
+        assert np.allclose(tvec[b], otv, rtol=1e-6, atol=1e-6), (b, tvec[b], otv)
+        pr = orc.project_points(obj[b, :npts[b]], rvec[b], tvec[b], K, dist)
+        d = np.sqrt(((pr - img[b, :npts[b]]) ** 2).sum(axis=1))
+        assert abs(mae[b] - d.mean()) < 1e-6 and abs(rmse[b] - np.sqrt((d ** 2).mean())) < 1e-6
+
+
 def test_ippe_square_vs_oracle(ctx):
     G = _data.goldens()
     K, dist = _data.calibration("Logitec_A_1280-720_0.npz")
