@@ -30,7 +30,7 @@ json.dump({
     "raw": {"FETCH_SIZE_KiB_per_launch": f, "WRITE_SIZE_KiB_per_launch": w, "launches": [nf, nw]},
     "corrections": "FETCH_SIZE doubled (gfx950 tallies 128-B read requests at 64 B, MI355X_MICROARCH.md 'HBM'); "
                    "WRITE_SIZE taken as is; KiB = 1024 B.  Expected: reads 3 B/px x 512/480 strip halo = 3.2 B/px; "
-                   "writes 1 B/px gray + 3/8 B/px bit planes = 1.375 B/px.",
+                   "writes 3/8 B/px of bit planes (the pipeline instance stores no gray image).",
     "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb, "traffic_bytes_per_launch": fb + wb,
     "fetch_bytes_per_px": fb / px, "write_bytes_per_px": wb / px,
     "traffic_bytes_per_px": (fb + wb) / px, "algorithmic_bytes_per_px": 8.0,
