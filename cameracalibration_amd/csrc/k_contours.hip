@@ -482,8 +482,18 @@ __device__ __forceinline__ uint32_t from_partner(uint32_t v) {
 constexpr unsigned int kPoolBlock = 16384, kSlotBlock = 8, kTaskBlock = 128, kStoreBatch = 256;
 
 struct WaveQueue {
-    unsigned int lo = 0, hi = 0;
+    unsigned int lo = 0, hi = 0, base = 0;
     bool drained = false;
+    // The first batch of every wave is fixed (wave w of nWaves takes batch w), only the later ones come from the shared
+    // counter: thousands of waves that all start with an atomic on one address wait in line for it (same-address
+    // atomics are served one at a time), which was most of the run time of the passes with little work per item.
+    __device__ __forceinline__ void start(unsigned int wave, unsigned int nWaves, unsigned int n, unsigned int batch) {
+        base = nWaves * batch;
+        const unsigned int b = wave * batch;
+        lo = b < n ? b : n;
+        hi = b + batch < n ? b + batch : n;
+        if (base >= n) drained = true;
+    }
     // every lane calls this; returns the item index for lanes with want == true (rank order) or ~0u if none is left
     // for them right now.  `unit` lanes form one consumer (pairs: unit = 2, the even lane's want counts).
     template <int UNIT>
@@ -494,7 +504,7 @@ struct WaveQueue {
         if (lo == hi && !drained) {
             unsigned int b = 0;
             if (lane == 0) b = atomicAdd(head, batch);
-            b = __builtin_amdgcn_readfirstlane(b);
+            b = __builtin_amdgcn_readfirstlane(b) + base;
             lo = b < n ? b : n;
             hi = b + batch < n ? b + batch : n;
             if (b + batch >= n) drained = true;
@@ -586,6 +596,7 @@ __device__ __forceinline__ void adopt_orphans(WaveAlloc& slotA, WaveAlloc& taskA
 // (which made 94 % of the wave-steps idle).  Each step advances the candidate's forward tracer and, in
 // lock-step, a tracer walking the border the other way round; both look for a crack with a smaller key.
 constexpr int kShortBudget = 48;
+constexpr unsigned int kWalkBatch = 128, kResolveBatch = 64;
 constexpr unsigned int kShortBatch = 256, kShortPoolBlock = 2048, kLongStage = 64;
 
 __global__ __launch_bounds__(256) void k_trace_short(const uint32_t* __restrict__ planes, DetCfg cfg,
@@ -615,6 +626,7 @@ __global__ __launch_bounds__(256) void k_trace_short(const uint32_t* __restrict_
     };
 
     WaveQueue queue;
+    queue.start(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), gridDim.x * (blockDim.x >> 6), n, kShortBatch);
     WaveAlloc poolA, slotA, taskA;
     bool active = false, exhausted = false, isHole = false, bwActive = false;
     uint64_t c = 0;
@@ -833,6 +845,7 @@ __global__ __launch_bounds__(64) void k_seg_walk(const uint32_t* __restrict__ pl
     win.gx = win.gy = 0;
     win.valid = false;
     WaveQueue queue;
+    queue.start(blockIdx.x, gridDim.x, nItems, kWalkBatch);
 
     // Everything that touches global memory or is rare -- writing a finished segment's record, taking up the next
     // work item, moving a lane's window -- happens in a service phase every kService steps, for all lanes that need
@@ -877,7 +890,7 @@ __global__ __launch_bounds__(64) void k_seg_walk(const uint32_t* __restrict__ pl
             // ---- lanes without a next item draw one (its load is in flight while the current item is followed) ----
             {
                 const bool need = nextI == ~0u && !exhausted;
-                const unsigned int i = queue.pop<1>(need, &ctr->qWalk, nItems, 64u, lane);
+                const unsigned int i = queue.pop<1>(need, &ctr->qWalk, nItems, kWalkBatch, lane);
                 if (need) {
                     if (i != ~0u) {
                         nextI = i;
@@ -1003,13 +1016,14 @@ __global__ __launch_bounds__(64) void k_resolve(DetCfg cfg, const uint64_t* __re
     const unsigned int virtLo = segCap - min(ctr->nVirt, segCap - nItems);  // continuation ids are >= virtLo
     const unsigned int hopCap = (unsigned int)cfg.maxPerim + 4u * (unsigned int)kSegLen;  // no ring is longer (in segments) than this
     WaveQueue queue;
+    queue.start(blockIdx.x, gridDim.x, nCand, kResolveBatch);
     WaveAlloc poolA, slotA, taskA;
     bool exhausted = false;
 
     auto valid_id = [&](uint32_t v) { return v < nItems || (v >= virtLo && v < segCap); };
 
     for (;;) {
-        const unsigned int i = queue.pop<1>(!exhausted, &ctr->qResolve, nCand, 64u, lane);
+        const unsigned int i = queue.pop<1>(!exhausted, &ctr->qResolve, nCand, kResolveBatch, lane);
         const bool have = !exhausted && i != ~0u;
         if (!exhausted && i == ~0u && queue.empty()) exhausted = true;
         if (__all(exhausted)) break;
@@ -1138,6 +1152,7 @@ __global__ __launch_bounds__(64) void k_trace_store(const uint32_t* __restrict__
     win.gx = win.gy = 0;
     win.valid = false;
     WaveQueue queue;
+    queue.start(blockIdx.x, gridDim.x, n, kStoreBatch);
 
     for (;;) {
         {
