@@ -495,6 +495,7 @@ int camsync_create(camsync_ctx** out, int device, int max_h, int max_w, int max_
     b.copyCap = b.taskCap;
     HIPCHK(c, dalloc(&b.copies, b.copyCap));
     HIPCHK(c, dalloc(&b.quads, B * kQuadCap));
+    HIPCHK(c, dalloc(&b.persp, B * kQuadCap * 10));
     HIPCHK(c, dalloc(&b.qcount, B));
     HIPCHK(c, dalloc(&b.counters, 1));
     b.markerCap = (unsigned)(B * kMaxMarkerOut);
@@ -505,7 +506,7 @@ int camsync_create(camsync_ctx** out, int device, int max_h, int max_w, int max_
     HIPCHK(c, dalloc(&b.outCounts, B));
     HIPCHK(c, dalloc(&b.outRejected, B * kMaxRejectedOut * 8));
     HIPCHK(c, dalloc(&b.outRejCounts, B));
-    HIPCHK(c, dalloc(&c->d_dict, 1024));
+    HIPCHK(c, dalloc(&c->d_dict, 4 * 1024));  // the codes under the four rotations
     HIPCHK(c, dalloc(&c->d_expTab, 21 * 41));
     HIPCHK(c, dalloc(&c->d_anchorIds, kMaxAnchors));
     HIPCHK(c, dalloc(&c->d_anchorObj, kMaxAnchors * 12));
@@ -530,7 +531,7 @@ void camsync_destroy(camsync_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DetBuffers& b = c->buf;
     void* ptrs[] = {c->d_chessGray, c->d_chessS, c->d_chessR, c->d_chessCand, c->d_chessMax, c->d_chessCount, c->d_spIn, c->d_spOut, c->d_spN,
-                    c->d_umap, c->d_uout, c->d_in, c->d_bin, b.planes, b.gray, b.cand, b.candLong, b.contours, b.pool, b.tasks, b.seeds, b.seg, b.hashKeys, b.hashVals, b.chain, b.copies, b.quads, b.qcount, b.counters, b.markers,
+                    c->d_umap, c->d_uout, c->d_in, c->d_bin, b.planes, b.gray, b.cand, b.candLong, b.contours, b.pool, b.tasks, b.seeds, b.seg, b.hashKeys, b.hashVals, b.chain, b.copies, b.quads, b.persp, b.qcount, b.counters, b.markers,
                     b.outIds, b.outCorners, b.rawCorners, b.outCounts, b.outRejected, b.outRejCounts, c->d_dict, c->d_expTab,
                     c->d_obj, c->d_img, c->d_npts, c->d_K, c->d_dist, c->d_rvec, c->d_tvec, c->d_mae, c->d_rmse, c->d_ok,
                     c->d_anchorIds, c->d_anchorObj, c->d_calObj, c->d_calImg, c->cal.intr, c->cal.ext, c->cal.intrTrial,
@@ -569,7 +570,11 @@ int camsync_set_dictionary(camsync_ctx* c, const uint16_t* codes, int n, int mar
     if (!codes || n < 1 || n > 1024) return fail(c, CAMSYNC_E_ARG, "dictionary must hold 1..1024 codes");
     if (marker_size < 1 || marker_size > 4) return fail(c, CAMSYNC_E_ARG, "marker_size must be 1..4 (16-bit codes)");
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipMemcpy(c->d_dict, codes, sizeof(uint16_t) * n, hipMemcpyHostToDevice));
+    // the dictionary search compares with every entry under its four rotations: laid out once here, [rotation][entry]
+    std::vector<uint16_t> rot((size_t)4 * n);
+    for (int r = 0; r < 4; r++)
+        for (int i = 0; i < n; i++) rot[(size_t)r * n + i] = (uint16_t)rotate_marker_code(codes[i], marker_size, r);
+    HIPCHK(c, hipMemcpy(c->d_dict, rot.data(), sizeof(uint16_t) * rot.size(), hipMemcpyHostToDevice));
     const int oldSize = c->markerSize;
     c->markerSize = marker_size;
     int rc = check_params(c, &c->params);

@@ -230,7 +230,8 @@ struct DetBuffers {
     float* outRejected;  // [B,kMaxRejectedOut,8]
     int32_t* outRejCounts;
     // tables
-    const uint16_t* dict;   // dictN codes
+    const uint16_t* dict;   // dictN codes under each of the four rotations, [rotation][entry]
+    double* persp;          // [B, kQuadCap, 10] inverse perspective map of every quad + usable flag (k_quad_persp)
     const float* expTab;    // [21][41] separable cornerSubPix weights
 };
 
@@ -300,6 +301,7 @@ struct CalibState {
 // offsets into the CAMSYNC_CALIB_WORK_DOUBLES work buffer: the record [S | rhs | err | change sums] (summed over
 // ranks), the focal-length normal equations, the replicated values of a trial step, the intrinsic step
 constexpr int kWAcc = 0, kWFocal = 160, kWRec = 168, kWDelta = 176;
+uint32_t rotate_marker_code(uint32_t code, int n, int r);
 int calib_lm_grid(int V);
 void launch_fill_i32(int32_t* dst, int n, int32_t value, hipStream_t st);
 void launch_calib_lm(const CalibState& s, int mode, double lambda, double* work, hipStream_t st);

@@ -4,11 +4,12 @@
 // Otsu threshold, per-cell majority vote, border test, dictionary lookup over
 // the four rotations.
 //
-// One wavefront per quad candidate.  Lane 0 solves the 8x8 system for the
-// perspective map (same elimination order as the CPU restatement, so the
-// nearest-neighbour sample positions round identically), the 64 lanes gather
-// the samples, build the histogram in LDS and vote the cells; the dictionary
-// is searched one entry per lane.
+// k_quad_persp solves the 8x8 systems for the perspective maps, one lane per
+// quad (same elimination order as the CPU restatement, so the nearest-neighbour
+// sample positions round identically); k_identify takes the quads in batches:
+// the 64 lanes of a wave gather a quad's samples, build the histogram in LDS and
+// vote the cells, Otsu's sequential loop runs one lane per quad, the dictionary
+// (all four rotations, laid out by the host) is searched one entry per lane.
 #include "internal.h"
 #include "wave_reduce.h"
 
@@ -25,6 +26,13 @@ __device__ __forceinline__ double lane_get(double v, int src) {
     return __hiloint2double(hi, lo);
 }
 
+// a wavefront's LDS operations execute in order: between its own phases only the compiler must keep the order
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ int wave_sum_i(int v) {
     return wave_allreduce(v, [](int a, int b) { return a + b; });
 }
@@ -32,41 +40,105 @@ __device__ __forceinline__ long long wave_sum_ll(long long v) {
     return wave_allreduce(v, [](long long a, long long b) { return a + b; });
 }
 
-// Code of a markerSize x markerSize bit grid (given as a row-major MSB-first
-// integer) seen under rotation r, as Dictionary::getByteListFromBits lays the
-// four rotations out.
-__device__ __forceinline__ uint32_t rotate_code(uint32_t code, int n, int r) {
-    if (r == 0) return code;
-    uint32_t out = 0;
-    for (int row = 0; row < n; row++)
-        for (int col = 0; col < n; col++) {
-            int sr, sc;
-            if (r == 1) { sr = col; sc = n - 1 - row; }
-            else if (r == 2) { sr = n - 1 - row; sc = n - 1 - col; }
-            else { sr = n - 1 - col; sc = row; }
-            const uint32_t bit = (code >> (n * n - 1 - (sr * n + sc))) & 1u;
-            out = (out << 1) | bit;
+// Perspective maps, one lane per quad: getPerspectiveTransform(corners -> (0,0),(S-1,0),(S-1,S-1),(0,S-1)) and its
+// inverse.  The 8x9 system is eliminated in registers in the reference's order (partial pivoting, first row with the
+// largest magnitude), so the nearest-neighbour sample positions round as on the CPU.  It used to run inside
+// k_identify on nine lanes of a wave per quad; here a wave does 64 quads, and k_identify keeps its registers.
+// persp[q] = the nine entries of the inverse map, then 1.0 / 0.0 = usable / degenerate.
+__global__ __launch_bounds__(64) void k_quad_persp(const QuadRec* __restrict__ quads, const int* __restrict__ qcount, DetCfg cfg,
+                                                   double* __restrict__ persp) {
+    // (frame = the fast grid index: consecutive workgroups go to different XCDs, and a frame's first workgroup has most
+    // of its quads -- with the batch index fast, the busy workgroups all landed on half of the XCDs)
+    const int f = blockIdx.x;
+    const int nq = min(qcount[f], kQuadCap);
+    const int S = (cfg.markerSize + 2 * cfg.borderBits) * cfg.cellSize;
+    const double S1 = (double)(float)(S - 1);
+    for (int q = blockIdx.y * 64 + threadIdx.x; q < nq; q += gridDim.y * 64) {
+        const QuadRec* qr = &quads[(size_t)f * kQuadCap + q];
+        double A[8][9];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const double sx = qr->c[2 * r], sy = qr->c[2 * r + 1];
+            const double dx = (r == 1 || r == 2) ? S1 : 0., dy = (r >= 2) ? S1 : 0.;
+            A[r][0] = sx; A[r][1] = sy; A[r][2] = 1; A[r][3] = 0; A[r][4] = 0; A[r][5] = 0; A[r][6] = -sx * dx; A[r][7] = -sy * dx; A[r][8] = dx;
+            A[r + 4][0] = 0; A[r + 4][1] = 0; A[r + 4][2] = 0; A[r + 4][3] = sx; A[r + 4][4] = sy; A[r + 4][5] = 1;
+            A[r + 4][6] = -sx * dy; A[r + 4][7] = -sy * dy; A[r + 4][8] = dy;
         }
-    return out;
+        bool ok = true;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            int k = i;
+            double big = fabs(A[i][i]);
+#pragma unroll
+            for (int j = i + 1; j < 8; j++)
+                if (fabs(A[j][i]) > big) { big = fabs(A[j][i]); k = j; }
+            if (big < 2.220446049250313e-16) ok = false;  // (the lane goes on with numbers nobody reads)
+            // swap rows i and k (columns before i are not read again)
+#pragma unroll
+            for (int c = i; c < 9; c++) {
+                double rk = A[i][c];
+#pragma unroll
+                for (int j = i + 1; j < 8; j++) rk = (j == k) ? A[j][c] : rk;
+#pragma unroll
+                for (int j = i + 1; j < 8; j++) A[j][c] = (j == k) ? A[i][c] : A[j][c];
+                A[i][c] = rk;
+            }
+            const double d = -1 / A[i][i];
+#pragma unroll
+            for (int j = i + 1; j < 8; j++) {
+                const double alpha = A[j][i] * d;
+#pragma unroll
+                for (int c = i + 1; c < 9; c++) A[j][c] += alpha * A[i][c];
+            }
+        }
+        double x[8];
+#pragma unroll
+        for (int i = 7; i >= 0; i--) {
+            double sacc = A[i][8];
+#pragma unroll
+            for (int k = i + 1; k < 8; k++) sacc -= A[i][k] * x[k];
+            x[i] = sacc / A[i][i];
+        }
+        const double M8 = 1.0;
+        const double det = x[0] * (x[4] * M8 - x[5] * x[7]) - x[1] * (x[3] * M8 - x[5] * x[6]) + x[2] * (x[3] * x[7] - x[4] * x[6]);
+        if (!(det != 0)) ok = false;
+        double mi[9];
+        const double id = 1. / det;
+        mi[0] = (x[4] * M8 - x[5] * x[7]) * id;
+        mi[1] = (x[2] * x[7] - x[1] * M8) * id;
+        mi[2] = (x[1] * x[5] - x[2] * x[4]) * id;
+        mi[3] = (x[5] * x[6] - x[3] * M8) * id;
+        mi[4] = (x[0] * M8 - x[2] * x[6]) * id;
+        mi[5] = (x[2] * x[3] - x[0] * x[5]) * id;
+        mi[6] = (x[3] * x[7] - x[4] * x[6]) * id;
+        mi[7] = (x[1] * x[6] - x[0] * x[7]) * id;
+        mi[8] = (x[0] * x[4] - x[1] * x[3]) * id;
+        double* out = persp + ((size_t)f * kQuadCap + q) * 10;
+#pragma unroll
+        for (int i = 0; i < 9; i++) out[i] = ok ? mi[i] : 0.0;
+        out[9] = ok ? 1.0 : 0.0;
+    }
 }
 
-// Quads are taken eight at a time: getThreshVal_Otsu's loop carries (q1, mu1) from bin to bin through a division,
-// so it is sequential -- a few thousand dependent instructions that used to run on one lane of the wave while 63
-// waited, more than everything else in this kernel together.  With a batch, eight lanes run eight of those loops
-// side by side; sampling, histogram, votes and dictionary search stay 64 lanes per quad.
-constexpr int kIdBatch = 8;
+// Quads are taken 32 at a time by a workgroup of four waves.  Sampling, histogram, cell votes and dictionary search
+// are 64 lanes per quad (eight quads per wave, one after the other).  getThreshVal_Otsu's loop carries (q1, mu1) from
+// bin to bin through a division, so it is sequential: a few thousand dependent instructions per quad, which one wave
+// runs for the 32 quads side by side, one lane each, while the other three wait.
+constexpr int kIdBatch = 32, kIdWaves = 4, kIdPerWave = kIdBatch / kIdWaves;
 
-__global__ __launch_bounds__(64) void k_identify(const uint8_t* __restrict__ gray, int grayC, QuadRec* __restrict__ quads,
-                                                 const int* __restrict__ qcount, const uint16_t* __restrict__ dict,
-                                                 DetCfg cfg) {
-    extern __shared__ __align__(16) uint8_t s_imgs[];  // kIdBatch patches of imgStride bytes (LDS decides the occupancy)
-    __shared__ int s_histw[256];                       // the histogram being built (atomics)
+// ROUNDS x 64 >= samples of a patch (9: the reference's 24 x 24 patch; 16: the largest patch check_params lets through)
+template <int kIdRounds>
+__global__ __launch_bounds__(64 * kIdWaves) void k_identify(const uint8_t* __restrict__ gray, int grayC, QuadRec* __restrict__ quads,
+                                                            const int* __restrict__ qcount, const uint16_t* __restrict__ dictRot,
+                                                            const double* __restrict__ persp, DetCfg cfg) {
+    extern __shared__ __align__(16) uint8_t s_imgs[];  // kIdBatch patches of imgStride bytes
+    __shared__ int s_histw[kIdWaves][256];             // the histograms being built (atomics), one per wave
     __shared__ uint16_t s_hist[kIdBatch][256];         // the batch's histograms (counts <= 1024)
     __shared__ double s_mu[kIdBatch];
     __shared__ int s_first[kIdBatch], s_last[kIdBatch], s_mode[kIdBatch], s_thr[kIdBatch];
 
-    const int lane = threadIdx.x;
-    const int f = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int f = blockIdx.x;  // (fast index: see k_quad_persp)
     const int nq = min(qcount[f], kQuadCap);
     const int H = cfg.H, W = cfg.W;
     const int nb = cfg.markerSize + 2 * cfg.borderBits;
@@ -75,134 +147,82 @@ __global__ __launch_bounds__(64) void k_identify(const uint8_t* __restrict__ gra
     const GraySrc img{gray + (size_t)f * H * W * grayC, grayC, (uint32_t)(H * W - 1)};
     const int imgStride = (S * S + 15) & ~15;
     const int sy0 = lane / S, sx0 = lane - sy0 * S, sqy = 64 / S, sqx = 64 - sqy * S;
+    int* const histw = s_histw[wave];
+    // cells of the nb x nb grid that belong to the border (bit y * nb + x)
+    const int bb = cfg.borderBits, ms = cfg.markerSize;
+    uint64_t borderMask = 0;
+    for (int y = 0; y < nb; y++)
+        for (int x = 0; x < nb; x++)
+            if (!(y >= bb && y < nb - bb && x >= bb && x < nb - bb)) borderMask |= 1ull << (y * nb + x);
 
-    for (int base = blockIdx.x * kIdBatch; base < nq; base += gridDim.x * kIdBatch) {
+    for (int base = blockIdx.y * kIdBatch; base < nq; base += gridDim.y * kIdBatch) {
         const int nbq = min(kIdBatch, nq - base);
-        // ---- phase 1, quad by quad: perspective map, samples, histogram, mean / standard deviation ----
-        for (int b = 0; b < nbq; b++) {
-            __syncthreads();
-            const QuadRec* qr = &quads[(size_t)f * kQuadCap + base + b];
-            // getPerspectiveTransform(corners -> (0,0),(S-1,0),(S-1,S-1),(0,S-1)) and its inverse.
-            // The 8x9 system is eliminated with lane c holding column c in registers: every element update of the
-            // reference's row operations is independent, so the arithmetic (and hence the rounding of the sample
-            // positions) is the same as on one thread, without the serial trips through LDS.
+        __syncthreads();  // (the previous round's phase 3 has read what phase 1 overwrites)
+        // ---- phase 1, quad by quad in every wave: samples, histogram, mean / standard deviation ----
+        for (int b = wave * kIdPerWave; b < min(nbq, (wave + 1) * kIdPerWave); b++) {
+            const double* mp = persp + ((size_t)f * kQuadCap + base + b) * 10;
             double mi[9];
-            bool ok = true;
-            {
-                const double S1 = (double)(float)(S - 1);
-                double col[8];
-    #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const double sx = qr->c[2 * r], sy = qr->c[2 * r + 1];
-                    const double dx = (r == 1 || r == 2) ? S1 : 0., dy = (r >= 2) ? S1 : 0.;
-                    double top, bot;  // rows r and r + 4, column `lane`
-                    switch (lane) {
-                        case 0: top = sx; bot = 0; break;
-                        case 1: top = sy; bot = 0; break;
-                        case 2: top = 1; bot = 0; break;
-                        case 3: top = 0; bot = sx; break;
-                        case 4: top = 0; bot = sy; break;
-                        case 5: top = 0; bot = 1; break;
-                        case 6: top = -sx * dx; bot = -sx * dy; break;
-                        case 7: top = -sy * dx; bot = -sy * dy; break;
-                        case 8: top = dx; bot = dy; break;
-                        default: top = 0; bot = 0; break;
-                    }
-                    col[r] = top;
-                    col[r + 4] = bot;
-                }
-    #pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    // partial pivoting on column i (held by lane i): first row with the largest magnitude
-                    int k = i;
-                    double big = fabs(col[i]);
-    #pragma unroll
-                    for (int j = i + 1; j < 8; j++)
-                        if (fabs(col[j]) > big) { big = fabs(col[j]); k = j; }
-                    k = lane_get(k, i);
-                    big = lane_get(big, i);
-                    if (big < 2.220446049250313e-16) { ok = false; break; }
-                    // swap rows i and k
-                    double rk = col[i];
-    #pragma unroll
-                    for (int j = i + 1; j < 8; j++) rk = (j == k) ? col[j] : rk;
-    #pragma unroll
-                    for (int j = i + 1; j < 8; j++) col[j] = (j == k) ? col[i] : col[j];
-                    col[i] = rk;
-                    const double d = -1 / lane_get(col[i], i);
-    #pragma unroll
-                    for (int j = i + 1; j < 8; j++) {
-                        const double alpha = lane_get(col[j], i) * d;
-                        if (lane > i) col[j] += alpha * col[i];
-                    }
-                }
-                if (ok) {
-                    double x[8];
-    #pragma unroll
-                    for (int i = 7; i >= 0; i--) {
-                        double sacc = lane_get(col[i], 8);
-    #pragma unroll
-                        for (int k = i + 1; k < 8; k++) sacc -= lane_get(col[i], k) * x[k];
-                        x[i] = sacc / lane_get(col[i], i);
-                    }
-                    const double M8 = 1.0;
-                    const double det = x[0] * (x[4] * M8 - x[5] * x[7]) - x[1] * (x[3] * M8 - x[5] * x[6]) +
-                                       x[2] * (x[3] * x[7] - x[4] * x[6]);
-                    if (det == 0) ok = false;
-                    else {
-                        const double id = 1. / det;
-                        mi[0] = (x[4] * M8 - x[5] * x[7]) * id;
-                        mi[1] = (x[2] * x[7] - x[1] * M8) * id;
-                        mi[2] = (x[1] * x[5] - x[2] * x[4]) * id;
-                        mi[3] = (x[5] * x[6] - x[3] * M8) * id;
-                        mi[4] = (x[0] * M8 - x[2] * x[6]) * id;
-                        mi[5] = (x[2] * x[3] - x[0] * x[5]) * id;
-                        mi[6] = (x[3] * x[7] - x[4] * x[6]) * id;
-                        mi[7] = (x[1] * x[6] - x[0] * x[7]) * id;
-                        mi[8] = (x[0] * x[4] - x[1] * x[3]) * id;
-                    }
-                }
-                if (!ok) {
-    #pragma unroll
-                    for (int i = 0; i < 9; i++) mi[i] = 0;
-                }
-            }
-            for (int i = lane; i < 256; i += 64) s_histw[i] = 0;
+#pragma unroll
+            for (int i = 0; i < 9; i++) mi[i] = mp[i];
+            const bool ok = mp[9] != 0.0;
+            for (int i = lane; i < 256; i += 64) histw[i] = 0;
             uint8_t* const s_img = s_imgs + b * imgStride;
-            __syncthreads();
+            wave_lds_fence();
 
             // warpPerspective(INTER_NEAREST, constant 0 border)
             const int m2 = cell / 2;
             int sum = 0;
             long long sq = 0;
-            // sample p = lane + 64 k is (y, x); stepping by 64 samples without dividing
-            for (int p = lane, y = sy0, x = sx0; p < S * S; p += 64, y += sqy, x += sqx) {
-                if (x >= S) { x -= S; y++; }
-                int v = 0;
-                if (ok) {
-                    const double X0 = mi[0] * 0 + mi[1] * y + mi[2];
-                    const double Y0 = mi[3] * 0 + mi[4] * y + mi[5];
-                    const double W0 = mi[6] * 0 + mi[7] * y + mi[8];
-                    double Wd = W0 + mi[6] * x;
-                    Wd = Wd ? 1. / Wd : 0;
-                    const double fX = fmax(-2147483648.0, fmin(2147483647.0, (X0 + mi[0] * x) * Wd));
-                    const double fY = fmax(-2147483648.0, fmin(2147483647.0, (Y0 + mi[3] * x) * Wd));
-                    int X = (int)rint(fX), Y = (int)rint(fY);
-                    X = min(max(X, -32768), 32767);
-                    Y = min(max(Y, -32768), 32767);
-                    if (X >= 0 && X < W && Y >= 0 && Y < H) v = img.at((size_t)Y * W + X);
+            // sample p = lane + 64 k is (y, x); stepping by 64 samples without dividing.  All the samples of a quad are
+            // fetched before any is used: with one fetch per trip round the loop the wave waited for memory once per
+            // 64 samples, and those waits were most of this kernel's time.
+            int vals[kIdRounds];
+            {
+                int y = sy0, x = sx0;
+#pragma unroll
+                for (int k = 0; k < kIdRounds; k++) {
+                    if (x >= S) { x -= S; y++; }
+                    int v = 0;
+                    if (ok && lane + 64 * k < S * S) {
+                        const double X0 = mi[0] * 0 + mi[1] * y + mi[2];
+                        const double Y0 = mi[3] * 0 + mi[4] * y + mi[5];
+                        const double W0 = mi[6] * 0 + mi[7] * y + mi[8];
+                        double Wd = W0 + mi[6] * x;
+                        Wd = Wd ? 1. / Wd : 0;
+                        const double fX = fmax(-2147483648.0, fmin(2147483647.0, (X0 + mi[0] * x) * Wd));
+                        const double fY = fmax(-2147483648.0, fmin(2147483647.0, (Y0 + mi[3] * x) * Wd));
+                        int X = (int)rint(fX), Y = (int)rint(fY);
+                        X = min(max(X, -32768), 32767);
+                        Y = min(max(Y, -32768), 32767);
+                        if (X >= 0 && X < W && Y >= 0 && Y < H) v = img.at((size_t)Y * W + X);
+                    }
+                    vals[k] = v;
+                    y += sqy;
+                    x += sqx;
                 }
-                s_img[p] = (uint8_t)v;
-                atomicAdd(&s_histw[v], 1);
-                if (y >= m2 && y < S - m2 && x >= m2 && x < S - m2) {
-                    sum += v;
-                    sq += v * v;
+            }
+            {
+                int y = sy0, x = sx0;
+#pragma unroll
+                for (int k = 0; k < kIdRounds; k++) {
+                    if (x >= S) { x -= S; y++; }
+                    const int p = lane + 64 * k;
+                    if (p < S * S) {
+                        const int v = vals[k];
+                        s_img[p] = (uint8_t)v;
+                        atomicAdd(&histw[v], 1);
+                        if (y >= m2 && y < S - m2 && x >= m2 && x < S - m2) {
+                            sum += v;
+                            sq += v * v;
+                        }
+                    }
+                    y += sqy;
+                    x += sqx;
                 }
             }
             sum = wave_sum_i(sum);
             sq = wave_sum_ll(sq);
-            __syncthreads();
-
+            wave_lds_fence();
 
             const int nin = (S - 2 * m2) * (S - 2 * m2);
             const double mean = (double)sum / nin;
@@ -221,7 +241,7 @@ __global__ __launch_bounds__(64) void k_identify(const uint8_t* __restrict__ gra
                 bool any = false;
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    const int h = s_histw[4 * lane + k];
+                    const int h = histw[4 * lane + k];
                     s_hist[b][4 * lane + k] = (uint16_t)h;
                     part += (long long)(4 * lane + k) * h;
                     any = any || h != 0;
@@ -237,10 +257,11 @@ __global__ __launch_bounds__(64) void k_identify(const uint8_t* __restrict__ gra
                 s_last[b] = lastBin;
                 s_mu[b] = mu;
             }
+            wave_lds_fence();
         }
         __syncthreads();
         // ---- phase 2, one lane per quad: getThreshVal_Otsu_8u in the reference's operation order ----
-        if (lane < nbq && s_mode[lane] == 0) {
+        if (wave == 0 && lane < nbq && s_mode[lane] == 0) {
             const double scale = 1. / (S * S), mu = s_mu[lane];
             const uint16_t* __restrict__ h = s_hist[lane];
             double mu1 = 0, q1 = 0, max_sigma = 0;
@@ -262,8 +283,8 @@ __global__ __launch_bounds__(64) void k_identify(const uint8_t* __restrict__ gra
             s_thr[lane] = thr;
         }
         __syncthreads();
-        // ---- phase 3, quad by quad: cell votes, border test, dictionary ----
-        for (int b = 0; b < nbq; b++) {
+        // ---- phase 3, quad by quad in every wave: cell votes, border test, dictionary ----
+        for (int b = wave * kIdPerWave; b < min(nbq, (wave + 1) * kIdPerWave); b++) {
             QuadRec* qr = &quads[(size_t)f * kQuadCap + base + b];
             const int mode = s_mode[b];
             uint64_t bitsMask;  // bit (y*nb+x) of the nb x nb grid
@@ -284,17 +305,14 @@ __global__ __launch_bounds__(64) void k_identify(const uint8_t* __restrict__ gra
                 }
                 bitsMask = __ballot(bit);
             }
-            // border errors and inner code (nb*nb <= 64)
-            int borderErrors = 0;
+            if (nb * nb < 64) bitsMask &= (1ull << (nb * nb)) - 1ull;
+            // border errors and inner code, rows top to bottom, the left cell of a row in the higher bit
+            const int borderErrors = __popcll(bitsMask & borderMask);
             uint32_t code = 0;
-            const int bb = cfg.borderBits, ms = cfg.markerSize;
-            for (int y = 0; y < nb; y++)
-                for (int x = 0; x < nb; x++) {
-                    const uint32_t bv = (uint32_t)((bitsMask >> (y * nb + x)) & 1ull);
-                    const bool inner = (y >= bb && y < nb - bb && x >= bb && x < nb - bb);
-                    if (inner) code = (code << 1) | bv;
-                    else borderErrors += bv;
-                }
+            for (int y = bb; y < nb - bb; y++) {
+                const uint32_t row = (uint32_t)(bitsMask >> (y * nb + bb)) & ((1u << ms) - 1u);
+                code = (code << ms) | (__brev(row) >> (32 - ms));
+            }
             int id = -1, rot = 0;
             if (borderErrors <= cfg.maxBorderErrors) {
                 // Dictionary::identify: first entry (lowest id) whose best rotation is within maxCorrection
@@ -302,9 +320,9 @@ __global__ __launch_bounds__(64) void k_identify(const uint8_t* __restrict__ gra
                     const int m = m0 + lane;
                     int best = ms * ms + 1, bestRot = -1;
                     if (m < cfg.dictN) {
-                        const uint32_t dc = dict[m];
+#pragma unroll
                         for (int r = 0; r < 4; r++) {
-                            const int hd = __popc(rotate_code(dc, ms, r) ^ code);
+                            const int hd = __popc((uint32_t)dictRot[r * cfg.dictN + m] ^ code);
                             if (hd < best) { best = hd; bestRot = r; }
                         }
                     }
@@ -327,11 +345,32 @@ __global__ __launch_bounds__(64) void k_identify(const uint8_t* __restrict__ gra
 
 }  // namespace
 
+// Code of a markerSize x markerSize bit grid (a row-major MSB-first integer) seen under rotation r, as
+// Dictionary::getByteListFromBits lays the four rotations out.
+uint32_t rotate_marker_code(uint32_t code, int n, int r) {
+    if (r == 0) return code;
+    uint32_t out = 0;
+    for (int row = 0; row < n; row++)
+        for (int col = 0; col < n; col++) {
+            int sr, sc;
+            if (r == 1) { sr = col; sc = n - 1 - row; }
+            else if (r == 2) { sr = n - 1 - row; sc = n - 1 - col; }
+            else { sr = n - 1 - col; sc = row; }
+            const uint32_t bit = (code >> (n * n - 1 - (sr * n + sc))) & 1u;
+            out = (out << 1) | bit;
+        }
+    return out;
+}
+
 void launch_identify(const DetCfg& c, const DetBuffers& b, int B, hipStream_t st) {
-    // eight waves per frame, eight quads per wave and round (a frame of the benchmark scene has about 60)
     const int S = (c.markerSize + 2 * c.borderBits) * c.cellSize;
     const size_t lds = (size_t)kIdBatch * ((S * S + 15) & ~15);
-    hipLaunchKernelGGL(k_identify, dim3(8, B), dim3(64), lds, st, b.graySrc, b.graySrcC, b.quads, b.qcount, b.dict, c);
+    hipLaunchKernelGGL(k_quad_persp, dim3(B, 2), dim3(64), 0, st, b.quads, b.qcount, c, b.persp);
+    // four workgroups per frame, 32 quads per workgroup and round (a frame of the benchmark scene has about 60)
+    if (S * S <= 9 * 64)
+        hipLaunchKernelGGL(k_identify<9>, dim3(B, 4), dim3(64 * kIdWaves), lds, st, b.graySrc, b.graySrcC, b.quads, b.qcount, b.dict, b.persp, c);
+    else
+        hipLaunchKernelGGL(k_identify<16>, dim3(B, 4), dim3(64 * kIdWaves), lds, st, b.graySrc, b.graySrcC, b.quads, b.qcount, b.dict, b.persp, c);
 }
 
 }  // namespace camsync
