@@ -216,7 +216,7 @@ def PnP(image_points, object_points, mtx, dist, getMetrics=False):
         print(f"Object point n°: {len(object_points)}, Image point n°: {len(image_points)}")
         raise e
     if ok[0] == 2:
-        raise _hip.CamsyncError(-1, "solvePnP on non-coplanar object points is not supported by the HIP path")
+        raise _hip.CamsyncError(-1, "solvePnP needs at least 6 points when they are not coplanar (cv.error in the reference)")
     if ok[0] != 1:
         raise Exception("Could not solve PnP")
     metrics = {}
@@ -282,7 +282,7 @@ def _process_cameras_batched(fixedArucos, movingArucos, cameras, frames, metrics
             out.append(False)
             continue
         if ok == 2:
-            raise _hip.CamsyncError(-1, "solvePnP on non-coplanar object points is not supported by the HIP path")
+            raise _hip.CamsyncError(-1, "solvePnP needs at least 6 points when they are not coplanar (cv.error in the reference)")
         if ok != 1:
             raise Exception("Could not solve PnP")
         rvec, tvec = rvec.reshape(3, 1), tvec.reshape(3, 1)

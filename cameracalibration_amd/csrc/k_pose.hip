@@ -75,6 +75,114 @@ __device__ __forceinline__ void eigen3(const double* Ain, double* w, double* V) 
     sort_pair3<1, 2>(w, V);
 }
 
+// 3x3 SVD A = U diag(w) Vt through the eigen-decomposition of AtA (the restatement's svd3).
+__device__ __forceinline__ void svd3(const double* A, double* U, double* w, double* Vt) {
+    double AtA[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            double s = 0;
+#pragma unroll
+            for (int k = 0; k < 3; k++) s += A[k * 3 + i] * A[k * 3 + j];
+            AtA[i * 3 + j] = s;
+        }
+    double ev[3];
+    eigen3(AtA, ev, Vt);
+#pragma unroll
+    for (int i = 0; i < 3; i++) w[i] = sqrt(fmax(ev[i], 0.));
+    double u[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            double s = 0;
+#pragma unroll
+            for (int k = 0; k < 3; k++) s += A[r * 3 + k] * Vt[i * 3 + k];
+            u[i][r] = s;
+        }
+        const double nrm = sqrt(u[i][0] * u[i][0] + u[i][1] * u[i][1] + u[i][2] * u[i][2]);
+        if (nrm > 1e-12 * (w[0] + 1e-300)) {
+#pragma unroll
+            for (int r = 0; r < 3; r++) u[i][r] /= nrm;
+        } else if (i == 2) {
+            u[2][0] = u[0][1] * u[1][2] - u[0][2] * u[1][1];
+            u[2][1] = u[0][2] * u[1][0] - u[0][0] * u[1][2];
+            u[2][2] = u[0][0] * u[1][1] - u[0][1] * u[1][0];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int r = 0; r < 3; r++) U[r * 3 + i] = u[i][r];
+}
+
+// A wavefront's LDS operations execute in order: only the compiler must keep them in order.
+__device__ __forceinline__ void pose_lds_order() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Cyclic Jacobi eigen-decomposition of the symmetric 12 x 12 matrix A (LDS, row-major, overwritten), eigenvectors in the
+// rows of V (LDS): the rotations in the restatement's order, each applied by twelve lanes (one matrix element of a row
+// or column per lane), so every element sees the same arithmetic as on one thread.  Returns the row of V that belongs
+// to the smallest eigenvalue.
+__device__ __forceinline__ int wave_jacobi12(double* A, double* V, int lane) {
+    constexpr int n = 12;
+    for (int i = lane; i < n * n; i += 64) V[i] = (i / n == i % n) ? 1.0 : 0.0;
+    pose_lds_order();
+    for (int sweep = 0; sweep < 60; sweep++) {
+        double off = 0;
+        for (int i = 0; i < n; i++)
+            for (int j = i + 1; j < n; j++) off += A[i * n + j] * A[i * n + j];
+        if (off < 1e-300) break;
+        for (int p = 0; p < n; p++)
+            for (int q = p + 1; q < n; q++) {
+                const double apq = A[p * n + q];
+                if (fabs(apq) < 1e-300) continue;
+                const double app = A[p * n + p], aqq = A[q * n + q];
+                const double theta = (aqq - app) / (2 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1));
+                const double c = 1 / sqrt(t * t + 1), s = t * c;
+                pose_lds_order();
+                if (lane < n) {
+                    const double akp = A[lane * n + p], akq = A[lane * n + q];
+                    A[lane * n + p] = c * akp - s * akq;
+                    A[lane * n + q] = s * akp + c * akq;
+                }
+                pose_lds_order();
+                if (lane < n) {
+                    const double apk = A[p * n + lane], aqk = A[q * n + lane];
+                    A[p * n + lane] = c * apk - s * aqk;
+                    A[q * n + lane] = s * apk + c * aqk;
+                    const double vpk = V[p * n + lane], vqk = V[q * n + lane];
+                    V[p * n + lane] = c * vpk - s * vqk;
+                    V[q * n + lane] = s * vpk + c * vqk;
+                }
+                pose_lds_order();
+            }
+    }
+    // the restatement sorts the eigenvalues in descending order by selection and takes the last row
+    int order[n];
+    double w[n];
+#pragma unroll
+    for (int i = 0; i < n; i++) { w[i] = A[i * n + i]; order[i] = i; }
+#pragma unroll
+    for (int i = 0; i < n; i++) {
+        int m = i;
+#pragma unroll
+        for (int j = i + 1; j < n; j++)
+            if (w[j] > w[m]) m = j;
+        double tw = w[i]; int to = order[i];
+#pragma unroll
+        for (int j = 0; j < n; j++) {
+            if (j == m) { w[i] = w[j]; order[i] = order[j]; w[j] = tw; order[j] = to; }
+        }
+    }
+    return order[n - 1];
+}
+
 struct PoseSums {
     double JtJ[36];
     double Jte[6];
@@ -173,6 +281,7 @@ __device__ __forceinline__ bool damped_solve(const PoseSums& S, double lambda, b
 // Point i of a frame is held by lane i % 64 as its point i / 64 (PPL points per lane: up to 64 PPL points).
 template <int PPL>
 __global__ __launch_bounds__(64) void k_pnp(PnpArgs a) {
+    __shared__ double s_LL[144], s_VV[144];  // the non-planar initialisation's 12 x 12 system and its eigenvectors
     const int lane = threadIdx.x;
     for (int f = blockIdx.x; f < a.B; f += gridDim.x) {
         const int n = min(a.npts[f], min(a.N, 64 * PPL));
@@ -219,7 +328,74 @@ __global__ __launch_bounds__(64) void k_pnp(PnpArgs a) {
             double Wv[3], V[9];
             eigen3(MM, Wv, V);
             if (!(Wv[2] / Wv[1] < 1e-3)) {
-                status = 2;  // non-planar object: not handled by this kernel (caller reports it)
+                // ---- non-planar object: DLT on the 3x4 projection (at least 6 points) ----
+                if (n < 6) {
+                    status = 2;  // (cv.solvePnP raises here; the caller reports it)
+                } else {
+                    // L^T L of the 2n x 12 system [P 1 0 x P x; 0 P 1 y P y] (x, y negated normalised image points): its
+                    // blocks are four symmetric 4 x 4 moment matrices of (P, 1)
+                    double mA[10], mX[10], mY[10], mC[10];
+#pragma unroll
+                    for (int k = 0; k < PPL; k++) {
+                        const double a0 = active[k] ? 1.0 : 0.0;
+                        const double x = -xn[k], y = -yn[k];
+                        const double ph[4] = {X[k] * a0, Y[k] * a0, Z[k] * a0, a0};
+                        int e = 0;
+#pragma unroll
+                        for (int a = 0; a < 4; a++)
+#pragma unroll
+                            for (int b = a; b < 4; b++, e++) {
+                                // one row's products as the restatement forms them: L0[a] L0[b] + L1[a] L1[b]
+                                const double pa = ph[a] * ph[b];
+                                const double px = (x * ph[a]) * ph[b], py = (y * ph[a]) * ph[b];
+                                const double pc = (x * ph[a]) * (x * ph[b]) + (y * ph[a]) * (y * ph[b]);
+                                mA[e] = k == 0 ? pa : mA[e] + pa;
+                                mX[e] = k == 0 ? px : mX[e] + px;
+                                mY[e] = k == 0 ? py : mY[e] + py;
+                                mC[e] = k == 0 ? pc : mC[e] + pc;
+                            }
+                    }
+                    {
+                        int e = 0;
+#pragma unroll
+                        for (int a = 0; a < 4; a++)
+#pragma unroll
+                            for (int b = a; b < 4; b++, e++) {
+                                const double sa = wsum(mA[e]), sx = wsum(mX[e]), sy = wsum(mY[e]), sc = wsum(mC[e]);
+                                if (lane == 0) {
+                                    s_LL[a * 12 + b] = s_LL[b * 12 + a] = sa;
+                                    s_LL[(4 + a) * 12 + 4 + b] = s_LL[(4 + b) * 12 + 4 + a] = sa;
+                                    s_LL[a * 12 + 8 + b] = s_LL[(8 + b) * 12 + a] = sx;
+                                    s_LL[b * 12 + 8 + a] = s_LL[(8 + a) * 12 + b] = sx;
+                                    s_LL[(4 + a) * 12 + 8 + b] = s_LL[(8 + b) * 12 + 4 + a] = sy;
+                                    s_LL[(4 + b) * 12 + 8 + a] = s_LL[(8 + a) * 12 + 4 + b] = sy;
+                                    s_LL[(8 + a) * 12 + 8 + b] = s_LL[(8 + b) * 12 + 8 + a] = sc;
+                                    s_LL[a * 12 + 4 + b] = s_LL[(4 + b) * 12 + a] = 0.0;
+                                    s_LL[b * 12 + 4 + a] = s_LL[(4 + a) * 12 + b] = 0.0;
+                                }
+                            }
+                    }
+                    pose_lds_order();
+                    const int row = wave_jacobi12(s_LL, s_VV, lane);
+                    const double* RR = s_VV + row * 12;
+                    double Rm[9] = {RR[0], RR[1], RR[2], RR[4], RR[5], RR[6], RR[8], RR[9], RR[10]};
+                    double tm[3] = {RR[3], RR[7], RR[11]};
+                    if (det3(Rm) < 0) {
+#pragma unroll
+                        for (int i = 0; i < 9; i++) Rm[i] = -Rm[i];
+#pragma unroll
+                        for (int i = 0; i < 3; i++) tm[i] = -tm[i];
+                    }
+                    const double sc = sqrt(Rm[0] * Rm[0] + Rm[1] * Rm[1] + Rm[2] * Rm[2] + Rm[3] * Rm[3] + Rm[4] * Rm[4] + Rm[5] * Rm[5] +
+                                           Rm[6] * Rm[6] + Rm[7] * Rm[7] + Rm[8] * Rm[8]);
+                    double U[9], ww[3], Vt[9], R[9];
+                    svd3(Rm, U, ww, Vt);
+                    mat3_mul(U, Vt, R);
+                    const double sN = sqrt(3.) / sc;  // ||R||_F / ||Rm||_F
+                    rodrigues_m2v(R, p);
+                    p[3] = tm[0] * sN; p[4] = tm[1] * sN; p[5] = tm[2] * sN;
+                    pose_lds_order();
+                }
             } else {
                 double Rt[9];
 #pragma unroll

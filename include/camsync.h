@@ -154,8 +154,11 @@ int camsync_debug_restore_capacity(camsync_ctx* ctx);
  * obj f32 [B,N,3], img f32 [B,N,2] (4 <= N <= 256: a wavefront per frame, up to
  * four points per lane), npts i32 [B] (<= N), K f64 [B or 1,3,3],
  * dist f64 [B or 1, ndist] (ndist <= 8: k1,k2,p1,p2,k3,k4,k5,k6),
- * per_frame_cam: 1 if K/dist are per frame.  Outputs (host): rvec,tvec f64
- * [B,3], ok u8 [B], mae,rmse f64 [B] (may be NULL). */
+ * per_frame_cam: 1 if K/dist are per frame.  Coplanar points start from a
+ * homography, other point sets (at least 6) from a DLT of the projection, as
+ * cvFindExtrinsicCameraParams2 does.  Outputs (host): rvec,tvec f64 [B,3],
+ * ok u8 [B] (1 solved, 0 no solution / fewer than 4 points, 2 fewer than 6
+ * points that are not coplanar), mae,rmse f64 [B] (may be NULL). */
 int camsync_pnp_batch(camsync_ctx* ctx, const float* obj, const float* img, const int32_t* npts,
                       int B, int N, const double* K, const double* dist, int ndist,
                       int per_frame_cam, double* rvec, double* tvec, uint8_t* ok,

@@ -269,6 +269,35 @@ def test_pnp_more_than_64_points_vs_oracle(ctx, n_markers):
         assert abs(mae[b] - d.mean()) < 1e-6 and abs(rmse[b] - np.sqrt((d ** 2).mean())) < 1e-6
 
 
+@pytest.mark.parametrize("N", [6, 24, 100])
+def test_pnp_non_coplanar_points_vs_oracle(ctx, N):
+    """cv.solvePnP(ITERATIVE) on a non-planar object starts from a DLT of the 3x4 projection instead of a homography
+    (OpenCV's cvFindExtrinsicCameraParams2; aruco.py:368 passes whatever the caller's markers span, e.g. markers that
+    were located in 3-D).  Fewer than 6 non-coplanar points are refused like OpenCV refuses them."""
+    from cameracalibration_amd import synth
+    K, dist = _data.calibration("Logitec_robot_1920-1080_10.npz")
+    rng = np.random.default_rng(77 + N)
+    B = 8
+    obj = rng.uniform(-120.0, 120.0, (B, N, 3)).astype(np.float32)
+    obj[:, :, 2] *= 0.5
+    img = np.zeros((B, N, 2), np.float32)
+    for b in range(B):
+        R, t = synth.look_at_pose(rng, (0.0, 0.0), dist_range=(500.0, 900.0))
+        rv = orc.rodrigues_mat2vec(R)
+        img[b] = (orc.project_points(obj[b], rv, t, K, dist) + rng.normal(0, 0.3, (N, 2))).astype(np.float32)
+    npts = np.full(B, N, np.int32)
+    rvec, tvec, ok, mae, rmse = ctx.pnp(obj, img, npts, K, dist)
+    for b in range(B):
+        o_ok, orv, otv = orc.solve_pnp(obj[b], img[b], K, dist)
+        assert ok[b] == 1 and o_ok, (b, ok[b], o_ok)
+        assert np.allclose(rvec[b], orv, rtol=1e-6, atol=1e-7), (b, rvec[b], orv)
+        assert np.allclose(tvec[b], otv, rtol=1e-6, atol=1e-5), (b, tvec[b], otv)
+        assert mae[b] < 1.5
+    # five non-coplanar points: no initialisation exists
+    _, _, ok5, _, _ = ctx.pnp(obj[:1, :5], img[:1, :5], np.array([5], np.int32), K, dist)
+    assert ok5[0] == 2 and not orc.solve_pnp(obj[0, :5], img[0, :5], K, dist)[0]
+
+
 def test_ippe_square_vs_oracle(ctx):
     G = _data.goldens()
     K, dist = _data.calibration("Logitec_A_1280-720_0.npz")
