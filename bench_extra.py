@@ -3,6 +3,7 @@
 
   * configs[2] on one GPU: detection of 3840x2160 frames with 40 markers each (frames/s, resident input; only with
     --frames4k N, see DESIGN.md §6);
+  * scene dependence: the reference's photo pic_2.png (textured desk scene) as a resident batch of 1280x720 frames;
   * config 5: wall latency of `processArucoFromMultipleCameras` for 8 cameras looking at one scene
     (p50 / p99 over repeated frame-sets, 1280x720 and 1920x1080), host frames in, Python mirror API,
     and the same eight 1080p frames as one batch (processArucoBatch).
@@ -29,6 +30,7 @@ def main():
     ap.add_argument("--steps4k", type=int, default=3, help="timed passes over the 4K frames")
     ap.add_argument("--only4k", action="store_true", help="skip the 8-camera latency legs")
     ap.add_argument("--sets", type=int, default=200)
+    ap.add_argument("--photo-frames", type=int, default=4096, help="frames of the photo leg (the reference's 1280x720 picture)")
     args = ap.parse_args()
 
     import torch
@@ -115,6 +117,59 @@ def main():
         _quiet.__exit__(None, None, None)
         print(json.dumps(out))
         return
+
+    # ---- scene dependence: the reference's own photos (1280x720, textured background) as a resident batch ----
+    try:
+        photos = [_data.load_bgr("pic_2.png")]
+        h, w = photos[0].shape[:2]
+        n = args.photo_frames
+        base = torch.stack([torch.from_numpy(np.ascontiguousarray(p)).to(dev) for p in photos])
+        g = torch.Generator(device=dev).manual_seed(11)
+        frames = torch.empty((n, h, w, 3), dtype=torch.uint8, device=dev)
+        for b0 in range(0, n, 64):
+            nb = min(64, n - b0)
+            idx = torch.arange(b0, b0 + nb, device=dev) % len(photos)
+            noise = torch.randn((nb, h, w, 3), generator=g, device=dev, dtype=torch.float32) * 1.0
+            frames[b0:b0 + nb] = (base[idx].to(torch.float32) + noise).round_().clamp_(0, 255).to(torch.uint8)
+        Kp, dp = _data.calibration("Logitec_A_1280-720_0.npz")
+        MM = 16
+        d_ids = torch.full((n, MM), -1, dtype=torch.int32, device=dev)
+        d_cor = torch.zeros((n, MM, 4, 2), dtype=torch.float32, device=dev)
+        d_cnt = torch.zeros((n,), dtype=torch.int32, device=dev)
+        d_rv = torch.zeros((n, 3), dtype=torch.float64, device=dev)
+        d_tv = torch.zeros((n, 3), dtype=torch.float64, device=dev)
+        d_ok = torch.zeros((n,), dtype=torch.uint8, device=dev)
+        ctx = _hip.Context(h, w, max_batch=n, device=0)
+        anchors = [10, 11, 14, 15]
+        anchor_obj = _data.v1_anchor_points(anchors)
+
+        def step_photo():
+            ctx.detect_pnp_resident(frames.data_ptr(), n, h, w, 3, anchors, anchor_obj, Kp, dp, MM, d_ids.data_ptr(),
+                                    d_cor.data_ptr(), d_cnt.data_ptr(), d_rv.data_ptr(), d_tv.data_ptr(), d_ok.data_ptr())
+
+        step_photo()
+        torch.cuda.synchronize()
+        lists = ctx.debug_lists()
+        ctx.enable_timers(True)
+        ctx.reset_timers()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            step_photo()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 3
+        tm = ctx.timers()
+        px_rate = n / dt * h * w
+        out["photos_1280x720"] = {
+            "frames": n, "frames_per_s": n / dt, "pixels_per_s": px_rate,
+            "as_1080p_frames_per_s_by_pixels": px_rate / (1920 * 1080),
+            "frames_with_pose": int(d_ok.to(torch.int64).sum().item()), "mean_markers_per_frame": float(d_cnt.to(torch.float64).mean().item()),
+            "stage_ms_per_step": {k: round(v[0] / 3, 3) for k, v in tm.items()}, "lists_used_and_capacity": lists,
+            "note": "the reference's pic_2.png (desk scene, 6 markers) + noise sigma 1 per frame; "
+                    "detect + PnP, resident input: how much the bench number depends on its flat synthetic background"}
+        del frames, ctx
+        torch.cuda.empty_cache()
+    except Exception as e:
+        out["photos_1280x720"] = {"error": "%s: %s" % (type(e).__name__, e)}
 
     # ---- config 5: 8 cameras, one scene, processArucoFromMultipleCameras (host frames, mirror API) ----
     K, dist = _data.calibration("Logitec_robot_1920-1080_10.npz")

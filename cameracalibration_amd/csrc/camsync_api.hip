@@ -476,15 +476,16 @@ int camsync_create(camsync_ctx** out, int device, int max_h, int max_w, int max_
     b.taskCap = (unsigned)std::min<size_t>((size_t)b.contourCap * 2 + b.poolCap / kCkStride + kLongWaves * 128 + (size_t)8192 * 32, 0x7FFFFFFFu);
     HIPCHK(c, dalloc(&b.tasks, b.taskCap));
     // long borders in segments (internal.h, SegRec): seeds, one record and one 128-byte chain chunk per segment, the
-    // seed -> id table (twice the seed list, a power of two).  Measured on the bench scene: ~1000 seeds and ~1500
-    // records per 1080p frame; on the 4K scene of configs[2] four times that.
-    b.seedCap = (unsigned)std::min<size_t>(B * std::max<size_t>(2048, px / 512) + 65536, 0x01FFFFFFu);
+    // seed -> id table (a power of two per bit plane).  Measured: ~1000 seeds and ~1500 records per 1080p frame of the
+    // bench scene, four times that on the 4K scene of configs[2], 1700 seeds per 1280x720 frame of the reference's
+    // photo pic_2.png (px / 540: textured scenes are what the budget of px / 256 is for).
+    b.seedCap = (unsigned)std::min<size_t>(B * std::max<size_t>(2048, px / 256) + 65536, 0x01FFFFFFu);
     HIPCHK(c, dalloc(&b.seeds, b.seedCap));
     b.segCap = (unsigned)std::min<size_t>(2 * (size_t)b.seedCap, 0x03FFFFFFu);
     HIPCHK(c, dalloc(&b.seg, b.segCap));
     {   // one sub-table per bit plane (allocated with the planes, ensure_planes)
         size_t hs = 1;
-        while (hs < std::max<size_t>(2048, px / 512)) hs <<= 1;
+        while (hs < std::max<size_t>(2048, px / 256)) hs <<= 1;
         b.hashMask = (unsigned)(hs - 1);
         HIPCHK(c, dalloc(&b.hashKeys, B * c->planeScales * hs));
         HIPCHK(c, dalloc(&b.hashVals, B * c->planeScales * hs));

@@ -215,14 +215,16 @@ def test_argument_errors_and_limits():
     p.maxMarkerPerimeterRate = 4.0
     ctx.set_params(p)
     ctx.detect(np.zeros((64, 64, 3), np.uint8))
-    # PnP: fewer than 4 points is not solvable, non-coplanar points are reported as unsupported (status 2)
+    # PnP: fewer than 4 points is not solvable; 8 points that are not coplanar are solved (DLT start), 5 are refused (status 2)
     K = np.array([[500.0, 0, 32], [0, 500.0, 32], [0, 0, 1]])
     obj = np.zeros((1, 8, 3), np.float32); img = np.zeros((1, 8, 2), np.float32)
     _, _, ok, _, _ = ctx.pnp(obj, img, [3], K, np.zeros(5))
     assert ok[0] == 0
     obj[0] = np.random.default_rng(1).normal(size=(8, 3)); obj[0, :, 2] += 5
     img[0] = (obj[0, :, :2] / obj[0, :, 2:3]) * 500 + 32
-    _, _, ok, _, _ = ctx.pnp(obj, img, [8], K, np.zeros(5))
+    rv, tv, ok, _, _ = ctx.pnp(obj, img, [8], K, np.zeros(5))
+    assert ok[0] == 1 and np.allclose(rv[0], 0, atol=1e-6) and np.allclose(tv[0], 0, atol=1e-5)  # the points were projected by the identity pose
+    _, _, ok, _, _ = ctx.pnp(obj, img, [5], K, np.zeros(5))
     assert ok[0] == 2
 
 
