@@ -18,8 +18,14 @@ namespace camsync {
 
 namespace {
 
-__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
-    return wave_allreduce(v, [](unsigned long long a, unsigned long long b) { return a > b ? a : b; });
+// The largest distance of the wave and the first position (smallest j) that has it.  Every lane brings its own best
+// (d, j) with j = ~0u when it has none.  Frames are at most 4095 pixels a side (check_frame_args), so squared distances
+// and cross products stay below 2^26: 32-bit integers, and two 32-bit reductions instead of one on 64-bit keys.
+struct Far { uint32_t d, j; };
+__device__ __forceinline__ Far wave_farthest(uint32_t d, uint32_t j) {
+    const uint32_t m = wave_allreduce(d, [](uint32_t a, uint32_t b) { return a > b ? a : b; });
+    const uint32_t jj = wave_allreduce(d == m ? j : 0xFFFFFFFFu, [](uint32_t a, uint32_t b) { return a < b ? a : b; });
+    return Far{m, jj};
 }
 
 struct IPt { int x, y; };
@@ -63,19 +69,18 @@ __global__ __launch_bounds__(64) void k_quad_fit(const ContourRec* __restrict__ 
         for (int it = 0; it < 3; it++) {
             pos = (pos + rs) % n;
             const IPt sp = unpack_pt(P(pos));
-            unsigned long long best = 0;
+            uint32_t bd = 0, bj = 0xFFFFFFFFu;
             for (int j = 1 + lane; j < n; j += 64) {
                 int idx = pos + j;
                 if (idx >= n) idx -= n;
                 const IPt p = unpack_pt(P(idx));
-                const long long dx = p.x - sp.x, dy = p.y - sp.y;
-                const unsigned long long d = (unsigned long long)(dx * dx + dy * dy);
-                const unsigned long long key = (d << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)j);
-                best = key > best ? key : best;
+                const int dx = p.x - sp.x, dy = p.y - sp.y;
+                const uint32_t d = (uint32_t)(__mul24(dx, dx) + __mul24(dy, dy));
+                if (d > bd) { bd = d; bj = (uint32_t)j; }  // (strict: the first of equal distances stays)
             }
-            best = wave_max_u64(best);
-            const unsigned long long maxd = best >> 32;
-            if (maxd > 0) rs = (int)(0xFFFFFFFFu - (unsigned)(best & 0xFFFFFFFFull));
+            const Far far = wave_farthest(bd, bj);
+            const uint32_t maxd = far.d;
+            if (maxd > 0) rs = (int)far.j;
             le_eps = (double)maxd <= eps;
         }
 
@@ -109,24 +114,23 @@ __global__ __launch_bounds__(64) void k_quad_fit(const ContourRec* __restrict__ 
             if (first != b) {
                 int L = b - a - 1;
                 if (L < 0) L += n;
-                const long long dx = ep.x - sp.x, dy = ep.y - sp.y;
-                unsigned long long best = 0;
+                const int dx = ep.x - sp.x, dy = ep.y - sp.y;
+                uint32_t bd = 0, bj = 0xFFFFFFFFu;
                 for (int t = lane; t < L; t += 64) {
                     int idx = first + t;
                     if (idx >= n) idx -= n;
                     const IPt p = unpack_pt(P(idx));
-                    long long d = (long long)(p.y - sp.y) * dx - (long long)(p.x - sp.x) * dy;
-                    if (d < 0) d = -d;
-                    const unsigned long long key = ((unsigned long long)d << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)t);
-                    best = key > best ? key : best;
+                    const int c = __mul24(p.y - sp.y, dx) - __mul24(p.x - sp.x, dy);
+                    const uint32_t d = (uint32_t)(c < 0 ? -c : c);
+                    if (d > bd) { bd = d; bj = (uint32_t)t; }
                 }
-                best = wave_max_u64(best);
-                const double maxd = (double)(best >> 32);
-                if ((best >> 32) > 0) {
-                    split = first + (int)(0xFFFFFFFFu - (unsigned)(best & 0xFFFFFFFFull));
+                const Far far = wave_farthest(bd, bj);
+                const double maxd = (double)far.d;
+                if (far.d > 0) {
+                    split = first + (int)far.j;
                     if (split >= n) split -= n;
                 }
-                le = maxd * maxd <= eps * (double)(dx * dx + dy * dy);
+                le = maxd * maxd <= eps * (double)(__mul24(dx, dx) + __mul24(dy, dy));
             } else {
                 le = true;
             }
