@@ -495,6 +495,8 @@ int camsync_create(camsync_ctx** out, int device, int max_h, int max_w, int max_
     HIPCHK(c, dalloc(&b.chain, (size_t)b.chainCap * 32));
     b.copyCap = b.taskCap;
     HIPCHK(c, dalloc(&b.copies, b.copyCap));
+    b.resolveWaves = (unsigned)std::min<size_t>(std::max<size_t>(B * 8, 64), 256 * 32);
+    HIPCHK(c, dalloc(&b.resolveLog, (size_t)b.resolveWaves * kResolveLogHops * 64));
     HIPCHK(c, dalloc(&b.quads, B * kQuadCap));
     HIPCHK(c, dalloc(&b.persp, B * kQuadCap * 10));
     HIPCHK(c, dalloc(&b.qcount, B));
@@ -532,7 +534,7 @@ void camsync_destroy(camsync_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DetBuffers& b = c->buf;
     void* ptrs[] = {c->d_chessGray, c->d_chessS, c->d_chessR, c->d_chessCand, c->d_chessMax, c->d_chessCount, c->d_spIn, c->d_spOut, c->d_spN,
-                    c->d_umap, c->d_uout, c->d_in, c->d_bin, b.planes, b.gray, b.cand, b.candLong, b.contours, b.pool, b.tasks, b.seeds, b.seg, b.hashKeys, b.hashVals, b.chain, b.copies, b.quads, b.persp, b.qcount, b.counters, b.markers,
+                    c->d_umap, c->d_uout, c->d_in, c->d_bin, b.planes, b.gray, b.cand, b.candLong, b.contours, b.pool, b.tasks, b.seeds, b.seg, b.hashKeys, b.hashVals, b.chain, b.copies, b.resolveLog, b.quads, b.persp, b.qcount, b.counters, b.markers,
                     b.outIds, b.outCorners, b.rawCorners, b.outCounts, b.outRejected, b.outRejCounts, c->d_dict, c->d_expTab,
                     c->d_obj, c->d_img, c->d_npts, c->d_K, c->d_dist, c->d_rvec, c->d_tvec, c->d_mae, c->d_rmse, c->d_ok,
                     c->d_anchorIds, c->d_anchorObj, c->d_calObj, c->d_calImg, c->cal.intr, c->cal.ext, c->cal.intrTrial,

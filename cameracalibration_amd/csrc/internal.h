@@ -119,6 +119,7 @@ constexpr uint32_t kSegSelf = 0xFFFFFFFFu;   // (start candidates only) the bord
 constexpr uint32_t kSegAbort = 0xFFFFFFFEu;  // (start candidates only) not the canonical start, or longer than allowed
 constexpr uint32_t kSegNone = 0xFFFFFFFDu;   // no record: a list overflowed
 constexpr uint32_t kSegPending = 0xFFFFFFFCu;  // ends at a seed whose id k_seg_link still has to look up (pad0 / pad1 say which)
+constexpr unsigned int kResolveLogHops = 128;  // records per border the log holds (longer rings are walked twice)
 constexpr int kSegLen = 256;                  // = kCkStride: one chain chunk per segment
 
 constexpr int kTraceWaves = 256 * 16;  // persistent single-wave workgroups of the long-border kernels
@@ -139,25 +140,28 @@ inline void debug_stage(hipStream_t st, const char* name) {
     std::fflush(stderr);
 }
 
+// Every counter sits in a cache line of its own: they are the targets of all the list appends and work-queue pops of
+// the pipeline, and atomics on one line are served one after the other by one L2 channel -- with all of them in one
+// 72-byte struct, the three allocators of k_resolve alone queued ~80 k atomics on that line per launch.
 struct Counters {
-    unsigned int nCand;
-    unsigned int nContours;
-    unsigned int nPool;
-    unsigned int nMarkers;
-    unsigned int overflow;  // 1 starts, 2 contours, 4 points, 8 quads, 32 markers, 64 store/copy tasks, 128 bad contour record, 512 border seeds / segments
-    unsigned int nLong;     // candidates handed from the short-trace pass to the long-trace pass
-    unsigned int qDecide;   // work-queue heads of the long-border kernels (lanes fetch their next border here)
-    unsigned int qStore;
-    unsigned int nTasks;    // store tasks appended by the decide passes
-    unsigned int qShort;    // work-queue head of the short-border kernel
-    unsigned int nTail;     // border pairs handed from the decide pass to its tail pass
-    unsigned int nChain;    // chain chunks handed out
-    unsigned int nCopy;     // copy tasks appended by the decide passes
-    unsigned int nSeeds;    // border seeds found by the start pass (see SegRec)
-    unsigned int nVirt;     // continuation segments handed out by the segment walkers (ids count down from segCap - 1)
-    unsigned int qWalk;     // work-queue heads of the segment walkers and of the resolve pass
-    unsigned int qResolve;
-    unsigned int pad;
+    alignas(128) unsigned int nCand;
+    alignas(128) unsigned int nContours;
+    alignas(128) unsigned int nPool;
+    alignas(128) unsigned int nMarkers;
+    alignas(128) unsigned int overflow;  // 1 starts, 2 contours, 4 points, 8 quads, 32 markers, 64 store/copy tasks, 128 bad contour record, 512 border seeds / segments
+    alignas(128) unsigned int nLong;     // candidates handed from the short-trace pass to the long-trace pass
+    alignas(128) unsigned int qDecide;   // work-queue heads of the long-border kernels (lanes fetch their next border here)
+    alignas(128) unsigned int qStore;
+    alignas(128) unsigned int nTasks;    // store tasks appended by the decide passes
+    alignas(128) unsigned int qShort;    // work-queue head of the short-border kernel
+    alignas(128) unsigned int nTail;     // border pairs handed from the decide pass to its tail pass
+    alignas(128) unsigned int nChain;    // chain chunks handed out
+    alignas(128) unsigned int nCopy;     // copy tasks appended by the decide passes
+    alignas(128) unsigned int nSeeds;    // border seeds found by the start pass (see SegRec)
+    alignas(128) unsigned int nVirt;     // continuation segments handed out by the segment walkers (ids count down from segCap - 1)
+    alignas(128) unsigned int qWalk;     // work-queue heads of the segment walkers and of the resolve pass
+    alignas(128) unsigned int qResolve;
+    alignas(128) unsigned int pad;
 };
 
 // The detection pipeline does not write the gray image when the fused K1+K2 kernel runs: it is a fifth of that
@@ -231,6 +235,8 @@ struct DetBuffers {
     int32_t* outRejCounts;
     // tables
     const uint16_t* dict;   // dictN codes under each of the four rotations, [rotation][entry]
+    uint4* resolveLog;      // [resolveWaves, kResolveLogHops, 64] records visited by k_resolve's first pass (chunk, start, len)
+    unsigned int resolveWaves;  // waves of k_resolve (each owns a slice of the log)
     double* persp;          // [B, kQuadCap, 10] inverse perspective map of every quad + usable flag (k_quad_persp)
     const float* expTab;    // [21][41] separable cornerSubPix weights
 };

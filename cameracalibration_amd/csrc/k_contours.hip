@@ -479,7 +479,7 @@ __device__ __forceinline__ uint32_t from_partner(uint32_t v) {
 // A wave takes work from a global queue in batches and hands the items to its idle lanes, and it reserves
 // output space (points, contour records, store tasks) in blocks that it sub-allocates itself: the global
 // counters are touched once per block instead of once per border (they are single hot addresses).
-constexpr unsigned int kPoolBlock = 16384, kSlotBlock = 8, kTaskBlock = 128, kStoreBatch = 256;
+constexpr unsigned int kSlotBlock = 8, kStoreBatch = 256;
 
 struct WaveQueue {
     unsigned int lo = 0, hi = 0, base = 0;
@@ -1005,11 +1005,27 @@ __global__ __launch_bounds__(256) void k_seg_link(SegRec* __restrict__ seg, unsi
 // records run once round the border.  The border is kept when no crack on it has a smaller raster key than the
 // candidate (it is the canonical start) and its length is within the perimeter bounds; its points are then the
 // candidate's own stretch followed by the ring from that first seed, cut off at the border's length.
+// exclusive prefix sum over the wave's lanes, and the total
+__device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, int lane, uint32_t& total) {
+    uint32_t s = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)s, d);
+        if (lane >= d) s += t;
+    }
+    total = (uint32_t)__shfl((int)s, 63);
+    return s - v;
+}
+
 __global__ __launch_bounds__(64) void k_resolve(DetCfg cfg, const uint64_t* __restrict__ candLong, unsigned int candCap,
                                                 unsigned int seedCap, const SegRec* __restrict__ seg, unsigned int segCap,
                                                 ContourRec* __restrict__ contours, unsigned int contourCap, unsigned int poolCap,
-                                                CopyTask* __restrict__ tasks, unsigned int taskCap, Counters* __restrict__ ctr) {
+                                                CopyTask* __restrict__ tasks, unsigned int taskCap, uint4* __restrict__ hopLog,
+                                                Counters* __restrict__ ctr) {
     const int lane = threadIdx.x;
+    // this wave's log of the records pass 1 visits: [hop][lane] = (chunk, start, len), so that pass 2 reads them back in
+    // order with loads that do not depend on one another instead of chasing the pointers a second time
+    uint4* const myLog = hopLog + (size_t)blockIdx.x * kResolveLogHops * 64 + lane;
     const unsigned int nSeeds = min(ctr->nSeeds, seedCap), nLong = min(ctr->nLong, candCap);
     const unsigned int nItems = min(nSeeds + nLong, segCap);
     const unsigned int nCand = nItems > nSeeds ? nItems - nSeeds : 0u;
@@ -1017,7 +1033,6 @@ __global__ __launch_bounds__(64) void k_resolve(DetCfg cfg, const uint64_t* __re
     const unsigned int hopCap = (unsigned int)cfg.maxPerim + 4u * (unsigned int)kSegLen;  // no ring is longer (in segments) than this
     WaveQueue queue;
     queue.start(blockIdx.x, gridDim.x, nCand, kResolveBatch);
-    WaveAlloc poolA, slotA, taskA;
     bool exhausted = false;
 
     auto valid_id = [&](uint32_t v) { return v < nItems || (v >= virtLo && v < segCap); };
@@ -1045,6 +1060,7 @@ __global__ __launch_bounds__(64) void k_resolve(DetCfg cfg, const uint64_t* __re
                 const SegRec r = seg[id];
                 if (r.next == kSegAbort || r.next == kSegNone || r.len > (uint32_t)kSegLen || hop > hopCap) { ok = false; break; }
                 own += r.len;
+                if (nrec < kResolveLogHops) myLog[(size_t)nrec * 64] = make_uint4(r.chunk, r.start, r.len, 0u);
                 nrec++;
                 minAll = min(minAll, r.minAll);
                 minEast = min(minEast, r.minEast);
@@ -1064,6 +1080,7 @@ __global__ __launch_bounds__(64) void k_resolve(DetCfg cfg, const uint64_t* __re
                     if (r.next == kSegNone || r.next == kSegAbort || r.next == kSegSelf || r.len > (uint32_t)kSegLen || !valid_id(r.next) ||
                         hop > hopCap) { ok = false; break; }
                     ring += r.len;
+                    if (nrec < kResolveLogHops) myLog[(size_t)nrec * 64] = make_uint4(r.chunk, r.start, r.len, 0u);
                     nrec++;
                     minAll = min(minAll, r.minAll);
                     minEast = min(minEast, r.minEast);
@@ -1077,27 +1094,43 @@ __global__ __launch_bounds__(64) void k_resolve(DetCfg cfg, const uint64_t* __re
             if (ok && (isHole ? minEast : minAll) < startKey) ok = false;  // a crack with a smaller key: not the canonical start
             if (ok && (len < (uint32_t)cfg.minPerim || len > (uint32_t)cfg.maxPerim)) ok = false;
         }
-        // ---- the wave hands out space border by border (uniform loop) ----
+        // ---- space for the batch's accepted borders: their sizes summed over the wave, ONE atomic per list and batch
+        //      (the exact amount: nothing is reserved and left unused).  Reserving border by border from per-wave blocks
+        //      cost ~80 k atomics per launch on three addresses, and those waited in line at the L2 for most of this
+        //      kernel's time. ----
         unsigned int myOff = ~0u, mySlot = ~0u, myTask = ~0u;
-        unsigned long long am = __ballot(have && ok);
-        while (am) {
-            const int l = __ffsll((long long)am) - 1;
-            am &= am - 1;
-            const unsigned int ll = (unsigned int)__builtin_amdgcn_readlane((int)len, l), nr = (unsigned int)__builtin_amdgcn_readlane((int)nrec, l);
-            uint2 left;
-            const unsigned int off = poolA.take(ll, kPoolBlock, &ctr->nPool, poolCap, 4u, ctr, lane, left);
-            const unsigned int slot = slotA.take(1, kSlotBlock, &ctr->nContours, contourCap, 2u, ctr, lane, left);
-            const unsigned int t0 = taskA.take(nr, kTaskBlock, &ctr->nCopy, taskCap, 64u, ctr, lane, left);
-            mark_empty_tasks(tasks, left.x, left.y, lane);
-            if (off == ~0u || slot == ~0u || t0 == ~0u) {
-                if (slot != ~0u) mark_empty_contours(contours, slot, slot + 1, lane);
-                if (t0 != ~0u) mark_empty_tasks(tasks, t0, t0 + nr, lane);
-                adopt_orphans(slotA, taskA, contours, tasks, lane);
-            }
-            if (lane == l && off != ~0u && slot != ~0u && t0 != ~0u) {
-                myOff = off;
-                mySlot = slot;
-                myTask = t0;
+        {
+            const bool acc = have && ok;
+            uint32_t totLen, totRec, totSl;
+            const uint32_t oLen = wave_excl_scan(acc ? len : 0u, lane, totLen);
+            const uint32_t oRec = wave_excl_scan(acc ? nrec : 0u, lane, totRec);
+            const uint32_t oSl = wave_excl_scan(acc ? 1u : 0u, lane, totSl);
+            if (totSl) {
+                unsigned int bPool = 0, bSlot = 0, bTask = 0;
+                if (lane == 0) {
+                    bPool = atomicAdd(&ctr->nPool, totLen);
+                    bSlot = atomicAdd(&ctr->nContours, totSl);
+                    bTask = atomicAdd(&ctr->nCopy, totRec);
+                }
+                bPool = __builtin_amdgcn_readfirstlane(bPool);
+                bSlot = __builtin_amdgcn_readfirstlane(bSlot);
+                bTask = __builtin_amdgcn_readfirstlane(bTask);
+                const bool poolFits = bPool <= poolCap && totLen <= poolCap - bPool;
+                const bool slotFits = bSlot <= contourCap && totSl <= contourCap - bSlot;
+                const bool taskFits = bTask <= taskCap && totRec <= taskCap - bTask;
+                if (poolFits && slotFits && taskFits) {
+                    if (acc) {
+                        myOff = bPool + oLen;
+                        mySlot = bSlot + oSl;
+                        myTask = bTask + oRec;
+                    }
+                } else {
+                    // a full list fails the call with CAMSYNC_E_CAPACITY; what was reserved below the capacities is
+                    // nobody's now and must read as empty (the next passes look at every entry below the count)
+                    if (lane == 0) atomicOr(&ctr->overflow, (poolFits ? 0u : 4u) | (slotFits ? 0u : 2u) | (taskFits ? 0u : 64u));
+                    mark_empty_contours(contours, min(bSlot, contourCap), (unsigned int)min((unsigned long long)bSlot + totSl, (unsigned long long)contourCap), lane);
+                    mark_empty_tasks(tasks, min(bTask, taskCap), (unsigned int)min((unsigned long long)bTask + totRec, (unsigned long long)taskCap), lane);
+                }
             }
         }
         // ---- pass 2: the record and one copy task per segment, in border order ----
@@ -1112,25 +1145,38 @@ __global__ __launch_bounds__(64) void k_resolve(DetCfg cfg, const uint64_t* __re
             r.hole = isHole ? 1 : 0;
             r.scanKey = pos + (isHole ? 1u : 0u);
             contours[mySlot] = r;
-            uint32_t emitted = 0, t = 0, id = nSeeds + i;
-            for (unsigned int hop = 0; hop < nrec; hop++) {
-                const SegRec sr = seg[id];
-                const uint32_t n = min(sr.len, len - emitted);
-                CopyTask k;
-                k.chunk = sr.chunk;
-                k.start = sr.start;
-                k.dst = myOff + emitted;
-                k.n = n;  // (n = 0 reads as an empty task)
-                tasks[myTask + t++] = k;
-                emitted += n;
-                id = sr.next;
-                if (id == kSegSelf) break;
+            uint32_t emitted = 0, t = 0;
+            if (nrec <= kResolveLogHops) {
+                for (unsigned int hop = 0; hop < nrec; hop++) {
+                    const uint4 e = myLog[(size_t)hop * 64];
+                    const uint32_t n = min(e.z, len - emitted);
+                    CopyTask k;
+                    k.chunk = e.x;
+                    k.start = e.y;
+                    k.dst = myOff + emitted;
+                    k.n = n;  // (n = 0 reads as an empty task)
+                    tasks[myTask + t++] = k;
+                    emitted += n;
+                }
+            } else {  // (more records than the log holds: once more along the pointers)
+                uint32_t id = nSeeds + i;
+                for (unsigned int hop = 0; hop < nrec; hop++) {
+                    const SegRec sr = seg[id];
+                    const uint32_t n = min(sr.len, len - emitted);
+                    CopyTask k;
+                    k.chunk = sr.chunk;
+                    k.start = sr.start;
+                    k.dst = myOff + emitted;
+                    k.n = n;
+                    tasks[myTask + t++] = k;
+                    emitted += n;
+                    id = sr.next;
+                    if (id == kSegSelf) break;
+                }
             }
             // (tasks reserved beyond the ones written cannot exist: pass 1 counted the same records)
         }
     }
-    mark_empty_contours(contours, slotA.cur, slotA.end, lane);
-    mark_empty_tasks(tasks, taskA.cur, taskA.end, lane);
 }
 
 // Write the points of the accepted borders: one lane per store task.
@@ -1311,8 +1357,8 @@ void launch_trace(const DetCfg& c, const DetBuffers& b, hipStream_t st) {
     hipLaunchKernelGGL(k_seg_link, dim3(256 * 8), dim3(256), 0, st, b.seg, b.segCap, b.seedCap, b.candCap, c.nScales, b.hashKeys,
                        b.hashVals, b.hashMask, b.counters);
     debug_stage(st, "seg_link");
-    hipLaunchKernelGGL(k_resolve, dim3(256 * 32), dim3(64), 0, st, c, b.candLong, b.candCap, b.seedCap, b.seg, b.segCap, b.contours,
-                       b.contourCap, b.poolCap, b.copies, b.copyCap, b.counters);
+    hipLaunchKernelGGL(k_resolve, dim3(b.resolveWaves), dim3(64), 0, st, c, b.candLong, b.candCap, b.seedCap, b.seg, b.segCap, b.contours,
+                       b.contourCap, b.poolCap, b.copies, b.copyCap, b.resolveLog, b.counters);
     debug_stage(st, "resolve");
     // points of the borders the short pass kept (followed once more from their start), then of the long ones
     hipLaunchKernelGGL(k_trace_store, dim3(256 * 4), dim3(64), 0, st, b.planes, c, b.tasks, b.taskCap, b.pool, b.poolCap, b.counters);

@@ -55,7 +55,7 @@ def test_capacity_overflow_is_loud():
     ctx.detect(np.zeros((480, 640, 3), np.uint8))  # the context stays usable
 
 
-@pytest.mark.parametrize("limit", [dict(points=2000), dict(points=17000), dict(contours=20), dict(tasks=100),
+@pytest.mark.parametrize("limit", [dict(points=2000), dict(points=4000), dict(contours=20), dict(tasks=100),
                                    dict(contours=37, tasks=61)])
 def test_contour_list_overflow_is_loud_and_harmless(limit):
     """The contour, point and store-task lists are sized for thousands of frames, so one small frame can only fill
