@@ -267,14 +267,12 @@ int ensure_planes(camsync_ctx* c, int nScales) {
     if (nScales <= c->planeScales) return CAMSYNC_OK;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->buf.planes) (void)hipFree(c->buf.planes);
-    if (c->buf.hashKeys) (void)hipFree(c->buf.hashKeys);
-    if (c->buf.hashVals) (void)hipFree(c->buf.hashVals);
+    if (c->buf.seedTable) (void)hipFree(c->buf.seedTable);
     c->buf.planes = nullptr;
-    c->buf.hashKeys = c->buf.hashVals = nullptr;
+    c->buf.seedTable = nullptr;
     c->planeScales = 0;
     HIPCHK(c, dalloc(&c->buf.planes, (size_t)c->maxB * nScales * plane_words(c->maxH, (c->maxW + 31) / 32)));
-    HIPCHK(c, dalloc(&c->buf.hashKeys, (size_t)c->maxB * nScales * ((size_t)c->buf.hashMask + 1)));
-    HIPCHK(c, dalloc(&c->buf.hashVals, (size_t)c->maxB * nScales * ((size_t)c->buf.hashMask + 1)));
+    HIPCHK(c, dalloc(&c->buf.seedTable, (size_t)c->maxB * nScales * seed_table_entries(c->maxH, c->maxW)));
     c->planeScales = nScales;
     return CAMSYNC_OK;
 }
@@ -287,7 +285,6 @@ int enqueue_detect(camsync_ctx* c, const uint8_t* d_in, int B, int H, int W, int
     if (cfg.maxPerim > 2 * kCkMax * kCkStride - 4)
         return fail(c, CAMSYNC_E_ARG, "maxMarkerPerimeterRate gives contours of up to %d points, the border follower handles %d",
                     cfg.maxPerim, 2 * kCkMax * kCkStride - 4);
-    HIPCHK(c, hipMemsetAsync(c->buf.hashKeys, 0, sizeof(uint32_t) * ((size_t)c->buf.hashMask + 1) * B * cfg.nScales, c->stream));
     const bool fused = gray_thresh_is_fused(cfg);
     if (!fused) {
         rcp = ensure_gray(c);
@@ -476,20 +473,14 @@ int camsync_create(camsync_ctx** out, int device, int max_h, int max_w, int max_
     b.taskCap = (unsigned)std::min<size_t>((size_t)b.contourCap * 2 + b.poolCap / kCkStride + kLongWaves * 128 + (size_t)8192 * 32, 0x7FFFFFFFu);
     HIPCHK(c, dalloc(&b.tasks, b.taskCap));
     // long borders in segments (internal.h, SegRec): seeds, one record and one 128-byte chain chunk per segment, the
-    // seed -> id table (a power of two per bit plane).  Measured: ~1000 seeds and ~1500 records per 1080p frame of the
+    // seed -> id table (one entry per pixel of the grid lines of every bit plane).  Measured: ~1000 seeds and ~1500 records per 1080p frame of the
     // bench scene, four times that on the 4K scene of configs[2], 1700 seeds per 1280x720 frame of the reference's
     // photo pic_2.png (px / 540: textured scenes are what the budget of px / 256 is for).
     b.seedCap = (unsigned)std::min<size_t>(B * std::max<size_t>(2048, px / 256) + 65536, 0x01FFFFFFu);
     HIPCHK(c, dalloc(&b.seeds, b.seedCap));
     b.segCap = (unsigned)std::min<size_t>(2 * (size_t)b.seedCap, 0x03FFFFFFu);
     HIPCHK(c, dalloc(&b.seg, b.segCap));
-    {   // one sub-table per bit plane (allocated with the planes, ensure_planes)
-        size_t hs = 1;
-        while (hs < std::max<size_t>(2048, px / 256)) hs <<= 1;
-        b.hashMask = (unsigned)(hs - 1);
-        HIPCHK(c, dalloc(&b.hashKeys, B * c->planeScales * hs));
-        HIPCHK(c, dalloc(&b.hashVals, B * c->planeScales * hs));
-    }
+    HIPCHK(c, dalloc(&b.seedTable, B * c->planeScales * seed_table_entries(max_h, max_w)));  // (reallocated with the planes, ensure_planes)
     b.ckpt = nullptr;
     b.chainCap = b.segCap;
     HIPCHK(c, dalloc(&b.chain, (size_t)b.chainCap * 32));
@@ -534,7 +525,7 @@ void camsync_destroy(camsync_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DetBuffers& b = c->buf;
     void* ptrs[] = {c->d_chessGray, c->d_chessS, c->d_chessR, c->d_chessCand, c->d_chessMax, c->d_chessCount, c->d_spIn, c->d_spOut, c->d_spN,
-                    c->d_umap, c->d_uout, c->d_in, c->d_bin, b.planes, b.gray, b.cand, b.candLong, b.contours, b.pool, b.tasks, b.seeds, b.seg, b.hashKeys, b.hashVals, b.chain, b.copies, b.resolveLog, b.quads, b.persp, b.qcount, b.counters, b.markers,
+                    c->d_umap, c->d_uout, c->d_in, c->d_bin, b.planes, b.gray, b.cand, b.candLong, b.contours, b.pool, b.tasks, b.seeds, b.seg, b.seedTable, b.chain, b.copies, b.resolveLog, b.quads, b.persp, b.qcount, b.counters, b.markers,
                     b.outIds, b.outCorners, b.rawCorners, b.outCounts, b.outRejected, b.outRejCounts, c->d_dict, c->d_expTab,
                     c->d_obj, c->d_img, c->d_npts, c->d_K, c->d_dist, c->d_rvec, c->d_tvec, c->d_mae, c->d_rmse, c->d_ok,
                     c->d_anchorIds, c->d_anchorObj, c->d_calObj, c->d_calImg, c->cal.intr, c->cal.ext, c->cal.intrTrial,

@@ -218,9 +218,7 @@ struct DetBuffers {
     unsigned int seedCap;
     SegRec* seg;         // [segCap] ids: [0, nSeeds) seeds, [nSeeds, nSeeds + nLong) start candidates, continuations from the top down
     unsigned int segCap;
-    uint32_t* hashKeys;  // seed -> id: one open-addressing sub-table of hashMask + 1 slots per bit plane (position + 1, 0 = empty)
-    uint32_t* hashVals;
-    unsigned int hashMask;
+    uint32_t* seedTable;  // seed -> id, one table per bit plane indexed by the seed's place on the grid lines (k_contours.hip)
     QuadRec* quads;      // [B,kQuadCap]
     int* qcount;         // [B]
     Counters* counters;
@@ -308,6 +306,7 @@ struct CalibState {
 // ranks), the focal-length normal equations, the replicated values of a trial step, the intrinsic step
 constexpr int kWAcc = 0, kWFocal = 160, kWRec = 168, kWDelta = 176;
 uint32_t rotate_marker_code(uint32_t code, int n, int r);
+size_t seed_table_entries(int H, int W);
 int calib_lm_grid(int V);
 void launch_fill_i32(int32_t* dst, int n, int32_t value, hipStream_t st);
 void launch_calib_lm(const CalibState& s, int mode, double lambda, double* work, hipStream_t st);

@@ -77,12 +77,26 @@ __device__ __forceinline__ uint32_t seed_columns(int bx, uint32_t north, uint32_
     return wm == 0 ? (north & 1u) : wm == kSeedGrid / 64 ? (south & 1u) : 0u;
 }
 
+// Seed -> id table of one bit plane, indexed by where seeds can be: the rows y = 0 (mod G/2) in full, then the columns
+// x = 0 (mod G/2).  Entries are written when a seed is listed and only ever read for positions the followers found to
+// be seeds, so the table is never cleared (k_seg_link checks the entry against the seed list: a stale entry of an
+// earlier call reads as "not listed").
+__host__ __device__ __forceinline__ size_t seed_table_size(int H, int W) {
+    return (size_t)(H / (kSeedGrid / 2) + 1) * W + (size_t)(W / (kSeedGrid / 2) + 1) * H;
+}
+__device__ __forceinline__ size_t seed_table_index(int H, int W, uint32_t pos) {
+    const int y = (int)(pos / (uint32_t)W), x = (int)(pos - (uint32_t)y * (uint32_t)W);
+    constexpr int G2 = kSeedGrid / 2;
+    if ((y & (G2 - 1)) == 0) return (size_t)(y / G2) * W + x;
+    return (size_t)(H / G2 + 1) * W + (size_t)(x / G2) * H + y;
+}
+
 constexpr int kStartCols = 62;  // useful block columns per wavefront (lanes 1..62)
 
 __global__ __launch_bounds__(64) void k_contour_starts(const uint32_t* __restrict__ planes, DetCfg cfg, int B, int bands,
                                                        int bandGroups, uint64_t* __restrict__ cand, unsigned int candCap,
                                                        uint64_t* __restrict__ seeds, unsigned int seedCap,
-                                                       Counters* __restrict__ ctr) {
+                                                       uint32_t* __restrict__ seedTable, Counters* __restrict__ ctr) {
     __shared__ uint64_t stage[kStage];
     __shared__ uint64_t seedStage[kSeedStage];
     unsigned int seedStaged = 0;  // uniform
@@ -92,6 +106,7 @@ __global__ __launch_bounds__(64) void k_contour_starts(const uint32_t* __restric
     const bool dropIsolated = cfg.minPerim > 1;
     const int lane = threadIdx.x;
     unsigned int staged = 0;  // uniform
+    uint32_t* myTable = seedTable;  // this plane's part of the seed table (set below)
 
     auto flush = [&]() {
         if (staged) {
@@ -114,7 +129,11 @@ __global__ __launch_bounds__(64) void k_contour_starts(const uint32_t* __restric
             g = __builtin_amdgcn_readfirstlane(g);
             if (g + seedStaged > seedCap && lane == 0) atomicOr(&ctr->overflow, 512u);
             const unsigned int fit = g >= seedCap ? 0u : min(seedStaged, seedCap - g);
-            for (unsigned int k = lane; k < fit; k += 64) seeds[g + k] = seedStage[k];
+            for (unsigned int k = lane; k < fit; k += 64) {
+                const uint64_t v = seedStage[k];
+                seeds[g + k] = v;
+                myTable[seed_table_index(H, W, (uint32_t)(v & 0xFFFFFFFFull))] = g + k;
+            }
             seedStaged = 0;
         }
     };
@@ -137,6 +156,7 @@ __global__ __launch_bounds__(64) void k_contour_starts(const uint32_t* __restric
     const uint32_t hm = !mine ? 0u : ((bx + 1) * 32 > W ? (1u << (W - bx * 32)) - 1u : 0xFFFFFFFFu);
     const uint32_t* const plane = planes + (size_t)fs * perPlane;
     const uint32_t f = fs / (unsigned int)S, sc = fs % (unsigned int)S;
+    myTable = seedTable + (size_t)fs * seed_table_size(H, W);
 
     // eight consecutive rows of this lane's column, starting at row 8 g (zero outside the plane)
     struct Rows { uint4 a, b; };
@@ -749,52 +769,6 @@ __global__ __launch_bounds__(256) void k_trace_short(const uint32_t* __restrict_
 }
 
 // ---- long borders in segments (internal.h, SegRec) ------------------------------------------------------
-// seed -> id table.  Every bit plane has its own open-addressing sub-table of (subMask + 1) slots, so that the inserts
-// and lookups of a plane stay within a few tens of kilobytes (the seeds of a plane are listed, and its borders followed,
-// close together in time); key = pixel position + 1, 0 = empty.
-__device__ __forceinline__ uint32_t seed_hash(uint32_t pos) {
-    uint32_t h = pos * 0x9E3779B1u;
-    return h ^ (h >> 15);
-}
-
-// one lane per seed
-__global__ __launch_bounds__(256) void k_seed_hash(const uint64_t* __restrict__ seeds, unsigned int seedCap, int S,
-                                                   uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                                                   unsigned int subMask, Counters* __restrict__ ctr) {
-    const unsigned int n = min(ctr->nSeeds, seedCap);
-    for (unsigned int i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
-        const uint64_t c = seeds[i];
-        const uint32_t key = (uint32_t)(c & 0xFFFFFFFFull) + 1u;
-        const size_t base = ((size_t)(uint32_t)(c >> 40) * S + (uint32_t)((c >> 36) & 7u)) * ((size_t)subMask + 1);
-        unsigned int slot = seed_hash(key) & subMask;
-        bool placed = false;
-        for (unsigned int probe = 0; probe <= subMask; probe++) {
-            const uint32_t prev = atomicCAS(&keys[base + slot], 0u, key);
-            if (prev == 0u || prev == key) {
-                vals[base + slot] = i;
-                placed = true;
-                break;
-            }
-            slot = (slot + 1) & subMask;
-        }
-        if (!placed) atomicOr(&ctr->overflow, 512u);  // more seeds in one plane than its sub-table holds
-    }
-}
-
-__device__ __forceinline__ uint32_t seed_lookup(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
-                                                unsigned int subMask, size_t planeId, uint32_t pos) {
-    const uint32_t key = pos + 1u;
-    const size_t base = planeId * ((size_t)subMask + 1);
-    unsigned int slot = seed_hash(key) & subMask;
-    for (unsigned int probe = 0; probe <= subMask; probe++) {
-        const uint32_t k = keys[base + slot];
-        if (k == key) return vals[base + slot];
-        if (k == 0u) break;
-        slot = (slot + 1) & subMask;
-    }
-    return kSegNone;
-}
-
 // Which crack of pixel (x, y) can be a seed: direction of the background neighbour (4 west, 0 east, 2 north, 6 south).
 // Rows 0 / G/2 (mod G) carry west / east seeds, the other rows north / south seeds at columns 0 / G/2 (mod G);
 // -1: the pixel cannot be a seed.  The start pass applies the same rule word-wide (seed_columns).
@@ -984,18 +958,22 @@ __global__ __launch_bounds__(64) void k_seg_walk(const uint32_t* __restrict__ pl
 
 // Turn "goes on at the seed at (plane, position)" into that seed's id: one lane per record.
 __global__ __launch_bounds__(256) void k_seg_link(SegRec* __restrict__ seg, unsigned int segCap, unsigned int seedCap,
-                                                  unsigned int candCap, int S, const uint32_t* __restrict__ hashKeys,
-                                                  const uint32_t* __restrict__ hashVals, unsigned int hashMask,
-                                                  Counters* __restrict__ ctr) {
+                                                  unsigned int candCap, int S, int H, int W, const uint64_t* __restrict__ seeds,
+                                                  const uint32_t* __restrict__ seedTable, Counters* __restrict__ ctr) {
     const unsigned int nSeeds = min(ctr->nSeeds, seedCap), nLong = min(ctr->nLong, candCap);
     const unsigned int nItems = min(nSeeds + nLong, segCap);
     const unsigned int nVirt = min(ctr->nVirt, segCap - nItems);
+    const size_t perPlane = seed_table_size(H, W);
     for (unsigned int t = blockIdx.x * 256u + threadIdx.x; t < nItems + nVirt; t += gridDim.x * 256u) {
         const unsigned int id = t < nItems ? t : segCap - 1u - (t - nItems);
         if (seg[id].next != kSegPending) continue;
-        const uint32_t pos = seg[id].pad0, fs = seg[id].pad1;
-        const uint32_t v = seed_lookup(hashKeys, hashVals, hashMask, (size_t)(fs >> 4) * S + (fs & 7u), pos);
-        if (v == kSegNone) atomicOr(&ctr->overflow, 512u);  // (a seed the start pass could not list)
+        const uint32_t pos = seg[id].pad0, fs = seg[id].pad1;  // position; frame << 4 | hole << 3 | scale
+        uint32_t v = seedTable[((size_t)(fs >> 4) * S + (fs & 7u)) * perPlane + seed_table_index(H, W, pos)];
+        // the entry is this call's only if the seed list agrees (the table is never cleared)
+        if (v >= nSeeds || seeds[v] != pack_cand(fs >> 4, 0u, fs & 7u, pos)) {
+            v = kSegNone;
+            atomicOr(&ctr->overflow, 512u);  // (a seed the start pass could not list)
+        }
         seg[id].next = v;
     }
 }
@@ -1340,22 +1318,19 @@ void launch_contour_starts(const DetCfg& c, const DetBuffers& b, int B, hipStrea
     bands = (totalGroups + bandGroups - 1) / bandGroups;
     const long long grid = waves * bands;
     hipLaunchKernelGGL(k_contour_starts, dim3((unsigned)grid), dim3(64), 0, st, b.planes, c, B, bands, bandGroups, b.cand, b.candCap,
-                       b.seeds, b.seedCap, b.counters);
+                       b.seeds, b.seedCap, b.seedTable, b.counters);
 }
 
 void launch_trace(const DetCfg& c, const DetBuffers& b, hipStream_t st) {
     hipLaunchKernelGGL(k_trace_short, dim3(256 * 8), dim3(256), 0, st, b.planes, c, b.cand, b.candCap, b.candLong,
                        b.contours, b.contourCap, b.poolCap, b.tasks, b.taskCap, b.counters);
     debug_stage(st, "trace_short");
-    // long borders: seeds -> table, segments (persistent: 16 single-wave workgroups per CU, 8 KiB of LDS each), decision
-    hipLaunchKernelGGL(k_seed_hash, dim3(256 * 4), dim3(256), 0, st, b.seeds, b.seedCap, c.nScales, b.hashKeys, b.hashVals, b.hashMask,
-                       b.counters);
-    debug_stage(st, "seed_hash");
+    // long borders: segments (persistent: single-wave workgroups, 8 KiB of LDS each), links, decision
     hipLaunchKernelGGL(k_seg_walk, dim3(kTraceWaves), dim3(64), 0, st, b.planes, c, b.seeds, b.seedCap, b.candLong, b.candCap, b.seg,
                        b.segCap, b.chain, b.counters);
     debug_stage(st, "seg_walk");
-    hipLaunchKernelGGL(k_seg_link, dim3(256 * 8), dim3(256), 0, st, b.seg, b.segCap, b.seedCap, b.candCap, c.nScales, b.hashKeys,
-                       b.hashVals, b.hashMask, b.counters);
+    hipLaunchKernelGGL(k_seg_link, dim3(256 * 8), dim3(256), 0, st, b.seg, b.segCap, b.seedCap, b.candCap, c.nScales, c.H, c.W,
+                       b.seeds, b.seedTable, b.counters);
     debug_stage(st, "seg_link");
     hipLaunchKernelGGL(k_resolve, dim3(b.resolveWaves), dim3(64), 0, st, c, b.candLong, b.candCap, b.seedCap, b.seg, b.segCap, b.contours,
                        b.contourCap, b.poolCap, b.copies, b.copyCap, b.resolveLog, b.counters);
@@ -1365,5 +1340,7 @@ void launch_trace(const DetCfg& c, const DetBuffers& b, hipStream_t st) {
     debug_stage(st, "trace_store");
     hipLaunchKernelGGL(k_trace_copy, dim3(256 * 8), dim3(256), 0, st, b.chain, b.copies, b.copyCap, b.chainCap, b.pool, b.poolCap, b.counters);
 }
+
+size_t seed_table_entries(int H, int W) { return seed_table_size(H, W); }
 
 }  // namespace camsync
