@@ -1249,6 +1249,42 @@ __global__ __launch_bounds__(64) void k_trace_store(const uint32_t* __restrict__
 // Write the points of the kept long borders: a half-wave per copy task.  Lane l of the half takes steps 8 l ..
 // 8 l + 7 of the piece's chain chunk; the pixel before step i is the piece's first pixel plus the sum of the
 // directions of steps 0 .. i - 1 (a prefix sum over the half-wave), and goes to dst + i or dst - i.
+// Inclusive prefix sum over each half of the wave (32 lanes) with DPP row shifts: no trip through LDS.
+__device__ __forceinline__ uint32_t half_wave_scan(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111 /* row_shr:1 */, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112 /* row_shr:2 */, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114 /* row_shr:4 */, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118 /* row_shr:8 */, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142 /* row_bcast:15 */, 0xa, 0xf, false);  // rows 1 and 3 take the row before
+    return v;
+}
+
+// The points of one copy task of at most 128 steps, a row of 32 consecutive steps at a time, one step per lane of the
+// half-wave: a prefix sum across the lanes places the row's points, and a store instruction writes 32 consecutive points.
+__device__ __forceinline__ void copy_short_task(const uint32_t* __restrict__ chain, const CopyTask& k, unsigned int cnt, bool good,
+                                                int l32, uint32_t* __restrict__ pool) {
+    uint32_t w[4];
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        const unsigned int j = (unsigned int)(32 * m + l32);
+        w[m] = (good && j < cnt) ? chain[(size_t)k.chunk * 32 + (j >> 3)] : 0u;
+    }
+    int cx = (int)(k.start & 0xFFFFu), cy = (int)(k.start >> 16);  // position of the row's first point
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        if ((unsigned int)(32 * m) >= cnt) break;  // (the same for all lanes of the half-wave)
+        const unsigned int j = (unsigned int)(32 * m + l32);
+        const int q = (int)((w[m] >> (4 * (j & 7u))) & 7u);
+        const int dx = fast_dx(q), dy = fast_dy(q);
+        // both sums in one word: every lane's step is biased by 1 so that the fields never go negative
+        const uint32_t inc = half_wave_scan((uint32_t)(dx + 1) | ((uint32_t)(dy + 1) << 16));
+        const int sx = (int)(inc & 0xFFFFu) - (l32 + 1), sy = (int)(inc >> 16) - (l32 + 1);  // steps 32 m .. j summed
+        if (good && j < cnt) pool[k.dst + j] = (uint32_t)(cx + sx - dx) | ((uint32_t)(cy + sy - dy) << 16);
+        cx += __shfl(sx, 31, 32);
+        cy += __shfl(sy, 31, 32);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_trace_copy(const uint32_t* __restrict__ chain, const CopyTask* __restrict__ copies,
                                                     unsigned int copyCap, unsigned int chainCap, uint32_t* __restrict__ pool,
                                                     unsigned int poolCap, Counters* __restrict__ ctr) {
@@ -1266,6 +1302,12 @@ __global__ __launch_bounds__(256) void k_trace_copy(const uint32_t* __restrict__
         // (empty entries have n = 0; anything else out of range is not a task)
         const bool good = cnt <= (unsigned int)kCkStride && k.chunk < chainCap && k.dst < poolCap &&
                           (rev ? cnt <= k.dst + 1u : cnt <= poolCap - k.dst);
+        // Most segments end at the next seed, a few dozen steps on: one to four rows of 32 steps cover the task, with
+        // a fraction of the work of the general case (eight steps per lane, points transposed through LDS).
+        if (!rev && cnt <= 128u) {
+            copy_short_task(chain, k, cnt, good, l32, pool);
+            continue;
+        }
         const uint32_t d = (good && (unsigned int)(8 * l32) < cnt) ? chain[(size_t)k.chunk * 32 + l32] : 0u;
         int ox[8], oy[8], x = 0, y = 0;
 #pragma unroll
@@ -1276,16 +1318,9 @@ __global__ __launch_bounds__(256) void k_trace_copy(const uint32_t* __restrict__
             x += fast_dx(q);
             y += fast_dy(q);
         }
-        // inclusive prefix sums of the lanes' totals within the half-wave
-        int sx = x, sy = y;
-#pragma unroll
-        for (int o = 1; o < 32; o <<= 1) {
-            const int tx = __shfl_up(sx, o, 32), ty = __shfl_up(sy, o, 32);
-            if (l32 >= o) {
-                sx += tx;
-                sy += ty;
-            }
-        }
+        // inclusive prefix sums of the lanes' totals within the half-wave (both in one word, biased by 8 per lane)
+        const uint32_t inc = half_wave_scan((uint32_t)(x + 8) | ((uint32_t)(y + 8) << 16));
+        const int sx = (int)(inc & 0xFFFFu) - 8 * (l32 + 1), sy = (int)(inc >> 16) - 8 * (l32 + 1);
         const int bx = (int)(k.start & 0xFFFFu) + sx - x, by = (int)(k.start >> 16) + sy - y;
         // through LDS, so that a store instruction writes 32 consecutive points instead of every eighth
         uint32_t* const mine = s_pts[threadIdx.x >> 5];
@@ -1303,6 +1338,7 @@ __global__ __launch_bounds__(256) void k_trace_copy(const uint32_t* __restrict__
         __builtin_amdgcn_wave_barrier();
     }
 }
+
 
 }  // namespace
 
