@@ -171,6 +171,34 @@ def main():
     except Exception as e:
         out["photos_1280x720"] = {"error": "%s: %s" % (type(e).__name__, e)}
 
+    # ---- host frames in: the PCIe-inclusive rate of detect + PnP, pageable against page-locked frame buffers ----
+    try:
+        h, w, n = 1080, 1920, 512
+        Kh, dh = _data.calibration("Logitec_robot_1920-1080_10.npz")
+        src = np.stack([synth.v1_frame(300 + i, Kh, H=h, W=w, device=dev, ss=2)[0].cpu().numpy() for i in range(8)])
+        pageable = np.ascontiguousarray(np.tile(src, (n // 8, 1, 1, 1)))
+        pinned = _hip.PinnedFrames(pageable.shape)
+        pinned.array[...] = pageable
+        ctx = _hip.Context(h, w, max_batch=n, device=0)
+        sheet = A.getArucosFromPaper(1)
+        anchors = [10, 11, 14, 15]
+        anchor_obj = _data.v1_anchor_points(anchors)
+        res = {}
+        for name, buf in (("pageable", pageable), ("page_locked", pinned.array)):
+            ctx.detect_pnp(buf, anchors, anchor_obj, Kh, dh)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                r = ctx.detect_pnp(buf, anchors, anchor_obj, Kh, dh)
+            dt = (time.perf_counter() - t0) / 3
+            res[name] = {"frames_per_s": n / dt, "GB_per_s_of_frames": n * h * w * 3 / dt / 1e9}
+        res["frames"] = n
+        res["note"] = "camsync_detect_pnp_batch on 512 host frames (1920x1080 BGR, 6.2 MB each) per call, results back on the host"
+        out["host_frames_1920x1080"] = res
+        pinned.close()
+        del ctx
+    except Exception as e:
+        out["host_frames_1920x1080"] = {"error": "%s: %s" % (type(e).__name__, e)}
+
     # ---- config 5: 8 cameras, one scene, processArucoFromMultipleCameras (host frames, mirror API) ----
     K, dist = _data.calibration("Logitec_robot_1920-1080_10.npz")
     for (h, w, camname, focus) in ((720, 1280, "Logitec_A", 0), (1080, 1920, "Logitec_robot", 10)):

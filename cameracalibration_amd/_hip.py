@@ -82,6 +82,8 @@ def load_library() -> C.CDLL:
         lib.camsync_device_count.restype = i32
         lib.camsync_create.argtypes = [C.POINTER(vp), i32, i32, i32, i32]
         lib.camsync_destroy.argtypes = [vp]
+        lib.camsync_host_alloc.argtypes = [C.POINTER(vp), C.c_size_t]
+        lib.camsync_host_free.argtypes = [vp]
         lib.camsync_destroy.restype = None
         lib.camsync_last_error.argtypes = [vp]
         lib.camsync_last_error.restype = C.c_char_p
@@ -154,6 +156,34 @@ def _cam(K, dist, B):
             raise ValueError("thin-prism / tilt distortion terms are not supported")
         d = np.ascontiguousarray(d[:, :8])
     return K, d, per_frame
+
+
+class PinnedFrames:
+    """A uint8 numpy array in page-locked host memory (camsync_host_alloc): frames written here are copied to the GPU
+    at the link's rate and without the driver's staging copy.  Keep the object alive as long as `.array` is used."""
+
+    def __init__(self, shape):
+        lib = load_library()
+        self._lib = lib
+        self._p = C.c_void_p()
+        n = int(np.prod(shape))
+        rc = lib.camsync_host_alloc(C.byref(self._p), C.c_size_t(n))
+        if rc:
+            raise CamsyncError(rc, "camsync_host_alloc(%d bytes) failed" % n)
+        buf = (C.c_uint8 * n).from_address(self._p.value)
+        self.array = np.frombuffer(buf, dtype=np.uint8).reshape(shape)
+
+    def close(self):
+        if self._p:
+            self.array = None
+            self._lib.camsync_host_free(self._p)
+            self._p = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Context:

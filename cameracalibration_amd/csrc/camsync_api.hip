@@ -519,6 +519,18 @@ int camsync_create(camsync_ctx** out, int device, int max_h, int max_w, int max_
     return CAMSYNC_OK;
 }
 
+int camsync_host_alloc(void** out, size_t bytes) {
+    if (!out || !bytes) return CAMSYNC_E_ARG;
+    *out = nullptr;
+    // portable: page-locked for every GPU of the process, not only the current one
+    return hipHostMalloc(out, bytes, hipHostMallocPortable) == hipSuccess ? CAMSYNC_OK : CAMSYNC_E_HIP;
+}
+
+int camsync_host_free(void* p) {
+    if (!p) return CAMSYNC_OK;
+    return hipHostFree(p) == hipSuccess ? CAMSYNC_OK : CAMSYNC_E_HIP;
+}
+
 void camsync_destroy(camsync_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);

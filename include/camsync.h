@@ -18,6 +18,7 @@
 #ifndef CAMSYNC_H
 #define CAMSYNC_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -73,6 +74,15 @@ int camsync_device_count(void);
 int camsync_create(camsync_ctx** out, int device, int max_h, int max_w, int max_batch);
 void camsync_destroy(camsync_ctx* ctx);
 const char* camsync_last_error(const camsync_ctx* ctx);
+
+/* Frame ingest (camera.py:104-118, :150-154: cv.VideoCapture hands the reference pageable numpy frames).  Host
+ * buffers from camsync_host_alloc are page-locked: a capture or decode library that writes its frames there (V4L2
+ * user pointers, a decoder's output surface) spares the staging copy the driver makes of pageable memory, and the
+ * host-to-device copies of the *_batch entry points run at the link's rate (measured: DESIGN.md section 6).  Any
+ * host pointer is accepted by those entry points; these two calls only provide the fast kind.  The memory is not
+ * tied to a context (it may be shared by the contexts of several GPUs). */
+int camsync_host_alloc(void** out, size_t bytes);
+int camsync_host_free(void* p);
 
 /* cv.aruco.DetectorParameters() (aruco.py:249-254). */
 void camsync_default_params(camsync_params* p);

@@ -246,3 +246,17 @@ def test_generic_threshold_windows_match_oracle():
     assert ids[0, :n].tolist() == oi.tolist()
     if n:
         assert np.abs(corners[0, :n] - oc).max() <= 1e-3
+
+
+def test_page_locked_frame_buffers_give_the_same_result():
+    """camsync_host_alloc (frame ingest): frames handed over in page-locked memory are the same frames."""
+    K, _ = _data.calibration("Logitec_robot_1920-1080_10.npz")
+    frames = np.stack([synth.v1_frame(i, K, ss=2)[0].numpy() for i in range(2)])
+    ctx = _hip.Context(1080, 1920, 2)
+    want = ctx.detect(frames)
+    pinned = _hip.PinnedFrames(frames.shape)
+    pinned.array[...] = frames
+    got = ctx.detect(pinned.array)
+    for a, b in zip(want, got):
+        assert np.array_equal(a, b)
+    pinned.close()
