@@ -343,19 +343,19 @@ struct Tracer {
     }
     __device__ __forceinline__ int dy(int d) const { return FLIP ? -dir_dy(d) : dir_dy(d); }
 
-    // returns false for a single-pixel border
-    __device__ __forceinline__ bool init(const uint32_t* plane, int WS, int x, int y, bool isHole) {
+    // Start at (x, y), whose neighbour mask `raw` (nb_mask, unmirrored) the caller has fetched (both tracers of a
+    // candidate start from the same pixel).  The first step goes to the first foreground neighbour clockwise from
+    // s_end - 1; returns false for a single-pixel border.
+    __device__ __forceinline__ bool init(uint32_t raw, int x, int y, bool isHole) {
         x0 = cx = x;
         y0 = cy = y;
         const int s_end = isHole ? 0 : 4;
-        s = s_end;
-        m = mask(plane, WS, x, y);
-        bool found = false;
-        for (int k = 0; k < 8; k++) {
-            s = (s - 1) & 7;
-            if (s == s_end) break;
-            if ((m >> s) & 1u) { found = true; break; }
-        }
+        m = FLIP ? flip_mask(raw) : raw;
+        // bit j of r = direction s_end + 1 + j: the directions s_end - 1, s_end - 2, ... s_end - 7 are bits 6, 5, ... 0
+        const int b = (s_end + 1) & 7;
+        const uint32_t r = ((m >> b) | (m << (8 - b))) & 0x7Fu;
+        const bool found = r != 0;
+        s = found ? (s_end + 1 + (31 - __clz(r))) & 7 : s_end;
         x1 = x0 + dir_dx(s);
         y1 = y0 + dy(s);
         return found;
@@ -674,8 +674,9 @@ __global__ __launch_bounds__(256) void k_trace_short(const uint32_t* __restrict_
                         startKey = y0 * W + x0;
                         count = 0;
                         active = true;
-                        if (!fw.init(plane, WS, x0, y0, isHole)) res = 1;  // a single pixel
-                        else bwActive = bw.init(plane, WS, x0, y0, isHole);
+                        const uint32_t raw = nb_mask(plane, WS, x0, y0);
+                        if (!fw.init(raw, x0, y0, isHole)) res = 1;  // a single pixel
+                        else bwActive = bw.init(raw, x0, y0, isHole);
                     }
                 } else if (queue.empty()) {
                     exhausted = true;
