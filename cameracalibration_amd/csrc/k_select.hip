@@ -69,6 +69,13 @@ __device__ int point_in_quad(const float* cnt, float px, float py) {
 }
 
 __device__ bool marker_in_marker(const float* m1, const float* m2) {
+    // a corner outside m2's bounding box is outside m2 (point_in_quad says so for such a point on every edge), and
+    // nearly all pairs of a frame end here: eight comparisons instead of four polygon tests
+    const float x0 = fminf(fminf(m2[0], m2[2]), fminf(m2[4], m2[6])), x1 = fmaxf(fmaxf(m2[0], m2[2]), fmaxf(m2[4], m2[6]));
+    const float y0 = fminf(fminf(m2[1], m2[3]), fminf(m2[5], m2[7])), y1 = fmaxf(fmaxf(m2[1], m2[3]), fmaxf(m2[5], m2[7]));
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        if (m1[2 * k] < x0 || m1[2 * k] > x1 || m1[2 * k + 1] < y0 || m1[2 * k + 1] > y1) return false;
     return point_in_quad(m2, m1[0], m1[1]) > 0 && point_in_quad(m2, m1[2], m1[3]) > 0 &&
            point_in_quad(m2, m1[4], m1[5]) > 0 && point_in_quad(m2, m1[6], m1[7]) > 0;
 }
@@ -113,23 +120,31 @@ __global__ __launch_bounds__(64) void k_select(const QuadRec* __restrict__ quads
         for (int k = 0; k < 8; k++) c[k] = (float)Q[i].c[k];
         s_perim[i] = perimeter4(c);
     }
+    // (scale asc, scan key desc) as one ascending key, staged in LDS: scan keys are pixel positions (< 2^24), scales < 8
+    for (int i = lane; i < n; i += 64) s_rank[i] = (int)((Q[i].scale << 24) | (0xFFFFFFu - (Q[i].scanKey & 0xFFFFFFu)));
     __syncthreads();
-    for (int i = lane; i < n; i += 64) {
-        const float pi = s_perim[i];
-        const uint32_t si = Q[i].scale, ki = Q[i].scanKey;
+    int myRank[NQ / 64];
+#pragma unroll
+    for (int t = 0; t < NQ / 64; t++) {
+        const int i = lane + 64 * t;
         int r = 0;
-        for (int j = 0; j < n; j++) {
-            if (j == i) continue;
-            const float pj = s_perim[j];
-            const uint32_t sj = Q[j].scale, kj = Q[j].scanKey;
-            bool before;  // j comes before i
-            if (pj != pi) before = pj > pi;
-            else if (sj != si) before = sj < si;
-            else before = kj > ki;
-            r += before ? 1 : 0;
+        if (i < n) {
+            const float pi = s_perim[i];
+            const uint32_t ki = (uint32_t)s_rank[i];
+            for (int j = 0; j < n; j++) {
+                const float pj = s_perim[j];
+                const uint32_t kj = (uint32_t)s_rank[j];
+                // j comes before i (never true for j == i)
+                const bool before = (pj != pi) ? pj > pi : kj < ki;
+                r += before ? 1 : 0;
+            }
         }
-        s_rank[i] = r;
+        myRank[t] = r;
     }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < NQ / 64; t++)
+        if (lane + 64 * t < n) s_rank[lane + 64 * t] = myRank[t];
     __syncthreads();
     for (int i = lane; i < n; i += 64) {
         const int r = s_rank[i];
@@ -152,10 +167,19 @@ __global__ __launch_bounds__(64) void k_select(const QuadRec* __restrict__ quads
     // ---- group near-duplicates ----
     const float rate = cfg.minMarkerDistanceRate;
     for (int i = 0; i < n; i++) {
+        const float cix = 0.25f * (s_c[i][0] + s_c[i][2] + s_c[i][4] + s_c[i][6]), ciy = 0.25f * (s_c[i][1] + s_c[i][3] + s_c[i][5] + s_c[i][7]);
         for (int j0 = i + 1; j0 < n; j0 += 64) {
             const int j = j0 + lane;
             bool close = false;
-            if (j < n) close = avg_distance(s_c[i], s_c[j]) < s_perim[j] * rate;
+            if (j < n) {
+                // the mean distance of matched corners is at least the distance of the centroids: pairs whose centroids
+                // are clearly further apart than the bound (1 % and a pixel of slack for rounding) cannot be close
+                const float thr = s_perim[j] * rate;
+                const float dx = 0.25f * (s_c[j][0] + s_c[j][2] + s_c[j][4] + s_c[j][6]) - cix;
+                const float dy = 0.25f * (s_c[j][1] + s_c[j][3] + s_c[j][5] + s_c[j][7]) - ciy;
+                const float lim = thr * 1.01f + 1.f;
+                if (dx * dx + dy * dy <= lim * lim) close = avg_distance(s_c[i], s_c[j]) < thr;
+            }
             unsigned long long m = __ballot(close);
             if (lane == 0) {
                 while (m) {
@@ -228,6 +252,16 @@ __global__ __launch_bounds__(64) void k_select(const QuadRec* __restrict__ quads
     }
     __syncthreads();
 
+    // first valid fall-back of every representative (smallest index), found by all lanes: the acceptance loop below runs
+    // on one lane and used to scan the candidates after each invalid one (s_rank is free again: reused)
+    for (int i = lane; i < n; i += 64) s_rank[i] = 0x7FFFFFFF;
+    __syncthreads();
+    for (int id = lane; id < n; id += 64) {
+        const int c = s_closeOf[id];
+        if (c >= 0 && s_valid[id]) atomicMin(&s_rank[c], id);
+    }
+    __syncthreads();
+
     if (lane == 0) {
         int maxDepth = 0;
         for (int i = ns - 1; i >= 0; i--) {
@@ -246,10 +280,8 @@ __global__ __launch_bounds__(64) void k_select(const QuadRec* __restrict__ quads
                 const int cand = s_sel[v];
                 bool valid = s_valid[cand] != 0;
                 if (!valid) {
-                    for (int id = cand + 1; id < n; id++) {
-                        if (s_closeOf[id] != cand) continue;
-                        if (s_valid[id]) { valid = true; s_use[v] = (short)id; break; }
-                    }
+                    const int id = s_rank[cand];
+                    if (id < n) { valid = true; s_use[v] = (short)id; }
                 }
                 s_acc[v] = valid ? 1 : 0;
             }
