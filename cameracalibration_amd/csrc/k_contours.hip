@@ -509,7 +509,7 @@ struct WaveQueue {
     // atomics are served one at a time), which was most of the run time of the passes with little work per item.
     __device__ __forceinline__ void start(unsigned int wave, unsigned int nWaves, unsigned int n, unsigned int batch) {
         base = nWaves * batch;
-        const unsigned int b = wave * batch;
+        const unsigned int b = wave < nWaves ? wave * batch : n;  // (wave >= nWaves: no batch of its own)
         lo = b < n ? b : n;
         hi = b + batch < n ? b + batch : n;
         if (base >= n) drained = true;
@@ -791,15 +791,22 @@ __device__ __forceinline__ bool seed_supported(uint32_t m, int dir) {
 // and goes on in it.  A start candidate also stops when it is back at its own start state (a border without seeds)
 // and gives up as soon as it meets a crack with a smaller raster key (it is not the canonical start) or exceeds the
 // length bound.  Lanes hold their next work item in registers, so that taking it up does not wait for memory.
-__global__ __launch_bounds__(64) void k_seg_walk(const uint32_t* __restrict__ planes, DetCfg cfg,
-                                                 const uint64_t* __restrict__ seeds, unsigned int seedCap,
-                                                 const uint64_t* __restrict__ candLong, unsigned int candCap,
-                                                 SegRec* __restrict__ seg, unsigned int segCap,
-                                                 uint32_t* __restrict__ chain, Counters* __restrict__ ctr) {
-    __shared__ __align__(8) uint32_t tile[kTileWords];
+// CANDS = false: the work items are the seeds; true: the long start candidates, whose step also keeps the start rule's
+// books (smaller key met: not the canonical start; closure without a seed; length bound).  Seeds are five items in six and
+// their step is a fifth shorter, so a wave works on one kind at a time (k_seg_walk).  `wave` of `nWaves` take a first
+// batch of items each without asking the shared counter (wave >= nWaves: this wave only helps to drain the queue).
+template <bool CANDS>
+__device__ __forceinline__ void seg_walk_items(const uint32_t* __restrict__ planes, const DetCfg& cfg,
+                                               const uint64_t* __restrict__ seeds, unsigned int seedCap,
+                                               const uint64_t* __restrict__ candLong, unsigned int candCap,
+                                               SegRec* __restrict__ seg, unsigned int segCap,
+                                               uint32_t* __restrict__ chain, Counters* __restrict__ ctr,
+                                               uint32_t* __restrict__ tile, unsigned int wave, unsigned int nWaves) {
     const int lane = threadIdx.x;
     const unsigned int nSeeds = min(ctr->nSeeds, seedCap), nLong = min(ctr->nLong, candCap);
     const unsigned int nItems = min(nSeeds + nLong, segCap);
+    const unsigned int base = CANDS ? nSeeds : 0u, nMine = CANDS ? nItems - min(nSeeds, nItems) : min(nSeeds, nItems);
+    unsigned int* const head = CANDS ? &ctr->qDecide : &ctr->qWalk;
     const int H = cfg.H, W = cfg.W, WS = cfg.WS, S = cfg.nScales;
     const size_t perPlane = plane_words(H, WS);
 
@@ -808,7 +815,8 @@ __global__ __launch_bounds__(64) void k_seg_walk(const uint32_t* __restrict__ pl
     // as a chain of scalar mask instructions: that doubled the instruction count of a step).
     //   st: 0 idle, 1 following a border, 2 segment complete (the service phase writes its record), 3 segment
     //       complete and the lane goes on in a continuation segment
-    int st = 0, isCand = 0, isHole = 0, fresh = 0;
+    constexpr int isCand = CANDS ? 1 : 0;
+    int st = 0, isHole = 0, fresh = 0;
     uint64_t c = 0, nextC = 0;
     uint32_t nextI = ~0u;   // the item this lane takes up next (~0u: none fetched)
     bool exhausted = false;  // the queue has nothing more for this lane
@@ -820,7 +828,7 @@ __global__ __launch_bounds__(64) void k_seg_walk(const uint32_t* __restrict__ pl
     win.gx = win.gy = 0;
     win.valid = false;
     WaveQueue queue;
-    queue.start(blockIdx.x, gridDim.x, nItems, kWalkBatch);
+    queue.start(wave, nWaves, nMine, kWalkBatch);
 
     // Everything that touches global memory or is rare -- writing a finished segment's record, taking up the next
     // work item, moving a lane's window -- happens in a service phase every kService steps, for all lanes that need
@@ -865,11 +873,11 @@ __global__ __launch_bounds__(64) void k_seg_walk(const uint32_t* __restrict__ pl
             // ---- lanes without a next item draw one (its load is in flight while the current item is followed) ----
             {
                 const bool need = nextI == ~0u && !exhausted;
-                const unsigned int i = queue.pop<1>(need, &ctr->qWalk, nItems, kWalkBatch, lane);
+                const unsigned int i = queue.pop<1>(need, head, nMine, kWalkBatch, lane);
                 if (need) {
                     if (i != ~0u) {
-                        nextI = i;
-                        nextC = i >= nSeeds ? candLong[i - nSeeds] : seeds[i];
+                        nextI = base + i;
+                        nextC = CANDS ? candLong[i] : seeds[i];
                     } else if (queue.empty()) {
                         exhausted = true;
                     }
@@ -880,7 +888,6 @@ __global__ __launch_bounds__(64) void k_seg_walk(const uint32_t* __restrict__ pl
                 c = nextC;
                 id = nextI;
                 nextI = ~0u;
-                isCand = id >= nSeeds ? 1 : 0;
                 const uint32_t pos = (uint32_t)(c & 0xFFFFFFFFull);
                 plane = planes + ((size_t)(uint32_t)(c >> 40) * S + (int)((c >> 36) & 7u)) * perPlane;
                 cx = (int)(pos % W);
@@ -913,10 +920,12 @@ __global__ __launch_bounds__(64) void k_seg_walk(const uint32_t* __restrict__ pl
         if (st == 1 && win.covers(cx, cy)) {  // (always covered, see above; a lane that is not waits for the next phase)
             const uint32_t m = win.mask(tile, lane, cx, cy);
             // a start candidate takes its start state (P0, s0) (s0 is never -1: single pixels end in the short pass)
-            const int s0 = fresh_dir(m, isHole != 0);
-            s = fresh ? (s0 < 0 ? 0 : s0) : s;
-            state0 = fresh ? pack_state(cx, cy, s) : state0;
-            fresh = 0;
+            if constexpr (CANDS) {
+                const int s0 = fresh_dir(m, isHole != 0);
+                s = fresh ? (s0 < 0 ? 0 : s0) : s;
+                state0 = fresh ? pack_state(cx, cy, s) : state0;
+                fresh = 0;
+            }
             // sweep counter-clockwise from s + 1 to the first foreground neighbour q; j background pixels are passed
             const int b0 = (s + 1) & 7;
             const uint32_t rot = ((m >> b0) | (m << (8 - b0))) & 0xFFu;
@@ -955,6 +964,22 @@ __global__ __launch_bounds__(64) void k_seg_walk(const uint32_t* __restrict__ pl
             st = (atSeed | abortNow | closed | tooLong) ? 2 : full ? 3 : 1;
         }
     }
+}
+
+// Every fourth wave starts on the start candidates (a sixth of the items, but they come without a seed to stop at and
+// their tail is the longer one), all waves then take the seeds, and whoever is done helps with what is left of the
+// candidates.
+__global__ __launch_bounds__(64) void k_seg_walk(const uint32_t* __restrict__ planes, DetCfg cfg,
+                                                 const uint64_t* __restrict__ seeds, unsigned int seedCap,
+                                                 const uint64_t* __restrict__ candLong, unsigned int candCap,
+                                                 SegRec* __restrict__ seg, unsigned int segCap,
+                                                 uint32_t* __restrict__ chain, Counters* __restrict__ ctr) {
+    __shared__ __align__(8) uint32_t tile[kTileWords];
+    const unsigned int nCandWaves = (gridDim.x + 3u) / 4u;
+    const bool candFirst = (blockIdx.x & 3u) == 0u;
+    if (candFirst) seg_walk_items<true>(planes, cfg, seeds, seedCap, candLong, candCap, seg, segCap, chain, ctr, tile, blockIdx.x >> 2, nCandWaves);
+    seg_walk_items<false>(planes, cfg, seeds, seedCap, candLong, candCap, seg, segCap, chain, ctr, tile, blockIdx.x, gridDim.x);
+    if (!candFirst) seg_walk_items<true>(planes, cfg, seeds, seedCap, candLong, candCap, seg, segCap, chain, ctr, tile, nCandWaves, nCandWaves);
 }
 
 // Turn "goes on at the seed at (plane, position)" into that seed's id: one lane per record.
