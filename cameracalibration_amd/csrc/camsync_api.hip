@@ -282,9 +282,9 @@ int enqueue_detect(camsync_ctx* c, const uint8_t* d_in, int B, int H, int W, int
     DetCfg cfg = make_cfg(c, H, W);
     int rcp = ensure_planes(c, cfg.nScales);
     if (rcp) return rcp;
-    if (cfg.maxPerim > 2 * kCkMax * kCkStride - 4)
+    if (cfg.maxPerim > kMaxBorder)
         return fail(c, CAMSYNC_E_ARG, "maxMarkerPerimeterRate gives contours of up to %d points, the border follower handles %d",
-                    cfg.maxPerim, 2 * kCkMax * kCkStride - 4);
+                    cfg.maxPerim, kMaxBorder);
     const bool fused = gray_thresh_is_fused(cfg);
     if (!fused) {
         rcp = ensure_gray(c);
@@ -459,18 +459,17 @@ int camsync_create(camsync_ctx** out, int device, int max_h, int max_w, int max_
     b.bin = nullptr;
     c->planeScales = 3;
     HIPCHK(c, dalloc(&b.planes, B * c->planeScales * plane_words(max_h, (max_w + 31) / 32)));
-    // (at least 2.5 MiB: after the short pass the start list holds the decide pass's tail records, 40 bytes per lane)
-    b.candCap = (unsigned)std::min<size_t>(std::max<size_t>(B * (px / 32), (size_t)kTraceWaves * kTailPairs * 10), 0x7FFFFFFFu);
+    b.candCap = (unsigned)std::min<size_t>(std::max<size_t>(B * (px / 32), 65536), 0x7FFFFFFFu);
     HIPCHK(c, dalloc(&b.cand, b.candCap));
     HIPCHK(c, dalloc(&b.candLong, b.candCap));
-    // (+ the blocks the persistent border-follower waves reserve and may leave partly unused)
-    // (decide pass: kTraceWaves waves + kTraceWaves * kTailPairs / 32 tail waves; short pass: 8192 waves)
-    constexpr size_t kLongWaves = (size_t)kTraceWaves + (size_t)kTraceWaves * kTailPairs / 32;
-    b.contourCap = (unsigned)std::min<size_t>(B * 4096 + (kLongWaves + 8192) * 32, 0x7FFFFFFFu);
+    // (+ slack for the blocks the persistent waves of the short-border and resolve passes reserve and may leave partly
+    // unused: kSlackWaves bounds the waves of one launch)
+    constexpr size_t kSlackWaves = 16384;
+    b.contourCap = (unsigned)std::min<size_t>(B * 4096 + kSlackWaves * 32, 0x7FFFFFFFu);
     HIPCHK(c, dalloc(&b.contours, b.contourCap));
-    b.poolCap = (unsigned)std::min<size_t>(B * std::max<size_t>(262144, px / 8) + kLongWaves * 16384 + (size_t)8192 * 2048, 0x7FFFFFFFu);
+    b.poolCap = (unsigned)std::min<size_t>(B * std::max<size_t>(262144, px / 8) + kSlackWaves * 8192, 0x7FFFFFFFu);
     HIPCHK(c, dalloc(&b.pool, b.poolCap));
-    b.taskCap = (unsigned)std::min<size_t>((size_t)b.contourCap * 2 + b.poolCap / kCkStride + kLongWaves * 128 + (size_t)8192 * 32, 0x7FFFFFFFu);
+    b.taskCap = (unsigned)std::min<size_t>((size_t)b.contourCap * 2 + b.poolCap / kCkStride + kSlackWaves * 64, 0x7FFFFFFFu);
     HIPCHK(c, dalloc(&b.tasks, b.taskCap));
     // long borders in segments (internal.h, SegRec): seeds, one record and one 128-byte chain chunk per segment, the
     // seed -> id table (one entry per pixel of the grid lines of every bit plane).  Measured: ~1000 seeds and ~1500 records per 1080p frame of the
@@ -481,7 +480,6 @@ int camsync_create(camsync_ctx** out, int device, int max_h, int max_w, int max_
     b.segCap = (unsigned)std::min<size_t>(2 * (size_t)b.seedCap, 0x03FFFFFFu);
     HIPCHK(c, dalloc(&b.seg, b.segCap));
     HIPCHK(c, dalloc(&b.seedTable, B * c->planeScales * seed_table_entries(max_h, max_w)));  // (reallocated with the planes, ensure_planes)
-    b.ckpt = nullptr;
     b.chainCap = b.segCap;
     HIPCHK(c, dalloc(&b.chain, (size_t)b.chainCap * 32));
     b.copyCap = b.taskCap;

@@ -123,9 +123,8 @@ constexpr unsigned int kResolveLogHops = 128;  // records per border the log hol
 constexpr int kSegLen = 256;                  // = kCkStride: one chain chunk per segment
 
 constexpr int kTraceWaves = 256 * 16;  // persistent single-wave workgroups of the long-border kernels
-constexpr int kCkStride = 256;         // a checkpoint (and a store task) every this many points
-constexpr int kTailPairs = 16;          // a decide wave with at most this many borders left hands them to the tail pass
-constexpr int kCkMax = 32;             // checkpoints per direction: covers borders up to 2 * 32 * 256 points
+constexpr int kCkStride = 256;         // points per copy task and chain chunk
+constexpr int kMaxBorder = 16380;       // longest border kept (maxMarkerPerimeterRate x the larger frame side must not exceed it)
 
 // Debugging aid (environment variable CAMSYNC_DEBUG_STAGES): wait for the stream after every kernel of the detection
 // sequence and report it on stderr, so that a failing kernel is named.  Off: one getenv at the first call.
@@ -150,16 +149,14 @@ struct Counters {
     alignas(128) unsigned int nMarkers;
     alignas(128) unsigned int overflow;  // 1 starts, 2 contours, 4 points, 8 quads, 32 markers, 64 store/copy tasks, 128 bad contour record, 512 border seeds / segments
     alignas(128) unsigned int nLong;     // candidates handed from the short-trace pass to the long-trace pass
-    alignas(128) unsigned int qDecide;   // work-queue heads of the long-border kernels (lanes fetch their next border here)
+    alignas(128) unsigned int qDecide;   // work-queue head of the segment walkers' start candidates (qWalk: their seeds)
     alignas(128) unsigned int qStore;
-    alignas(128) unsigned int nTasks;    // store tasks appended by the decide passes
+    alignas(128) unsigned int nTasks;    // store tasks appended by the short-border pass
     alignas(128) unsigned int qShort;    // work-queue head of the short-border kernel
-    alignas(128) unsigned int nTail;     // border pairs handed from the decide pass to its tail pass
-    alignas(128) unsigned int nChain;    // chain chunks handed out
-    alignas(128) unsigned int nCopy;     // copy tasks appended by the decide passes
+    alignas(128) unsigned int nCopy;     // copy tasks appended by k_resolve
     alignas(128) unsigned int nSeeds;    // border seeds found by the start pass (see SegRec)
     alignas(128) unsigned int nVirt;     // continuation segments handed out by the segment walkers (ids count down from segCap - 1)
-    alignas(128) unsigned int qWalk;     // work-queue heads of the segment walkers and of the resolve pass
+    alignas(128) unsigned int qWalk;     // work-queue heads of the segment walkers (seeds) and of the resolve pass
     alignas(128) unsigned int qResolve;
     alignas(128) unsigned int pad;
 };
@@ -209,7 +206,6 @@ struct DetBuffers {
     unsigned int poolCap;
     StoreTask* tasks;
     unsigned int taskCap;
-    uint2* ckpt;         // [kTraceWaves][32 pairs][2 directions][kCkMax] (start pixel, chain chunk) of the pieces of borders in flight
     uint32_t* chain;     // [chainCap][32] step directions, 8 per word
     unsigned int chainCap;
     CopyTask* copies;

@@ -25,16 +25,20 @@
 //       dropped as soon as either tracer meets a crack with a smaller raster
 //       key (it is not the canonical start) or the border closes below the
 //       minimum perimeter.  Noise specks and false starts end here.
-//   (3) Candidates still alive go to a work queue.  k_trace_decide<false> is a
-//       persistent kernel: two lanes share a border, one follows it forwards and
-//       one backwards inside private LDS windows of the plane, until they meet
-//       (length known) or one of them proves that the start is not canonical;
-//       borders within the perimeter bounds get a record, space in the point
-//       pool and are cut into store tasks of at most 256 points.  Waves left
-//       with a few very long borders hand them to k_trace_decide<true>, which
-//       packs them 32 to a wave.
-//   (4) k_trace_store re-follows every store task from its recorded state and
-//       writes the points to their final place.
+//   (3) Candidates still alive are long borders.  Border following is a walk on
+//       states (pixel, direction to the predecessor) under a bijective successor
+//       map, so it can start anywhere: k_contour_starts also lists *seeds*,
+//       cracks on a 64-pixel grid that are recognisable from the 3x3
+//       neighbourhood, and k_seg_walk follows every border from each seed (and
+//       from each candidate) to the next seed inside a private LDS window,
+//       recording chain codes: the longest dependent chain is one segment, not
+//       one border.  k_seg_link turns "ends at the seed at this position" into
+//       that seed's id; k_resolve walks each candidate's ring of segment records,
+//       applies the start rule (smallest key of the ring) and the perimeter
+//       bounds, and cuts accepted borders into copy tasks; k_trace_copy turns
+//       chain codes into points by prefix sums.
+//   (4) k_trace_store re-follows the (few) borders the short pass itself accepts
+//       and writes their points.
 // The traces only read the image, so they are independent of each other.
 #include "internal.h"
 
