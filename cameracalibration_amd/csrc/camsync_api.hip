@@ -165,6 +165,7 @@ DetCfg make_cfg(const camsync_ctx* c, int H, int W) {
     g.H = H;
     g.W = W;
     g.WS = (W + 31) / 32;
+    g.magicW = (uint32_t)(((1ull << 36) + (unsigned long long)W - 1ull) / (unsigned long long)W);
     g.nScales = (p.adaptiveThreshWinSizeMax - p.adaptiveThreshWinSizeMin) / p.adaptiveThreshWinSizeStep + 1;
     g.nScales = std::min(g.nScales, kMaxScales);
     for (int i = 0; i < g.nScales; i++) {

@@ -21,6 +21,7 @@ constexpr int kMaxAnchors = 64;
 // to kernels by value.
 struct DetCfg {
     int H, W;
+    uint32_t magicW;         // ceil(2^36 / W): pos / W = umulhi(pos, magicW) >> 4 for every raster position pos < 2^24 (row_of)
     int WS;                  // 32-bit words per bit-plane row = ceil(W/32)
     int nScales;
     int radius[kMaxScales];  // adaptive threshold half windows
@@ -45,6 +46,11 @@ struct DetCfg {
 // 32 words = one 128-byte line (word r of a block holds row r, bit i = pixel i).  A border follower then
 // touches one or two lines per neighbourhood instead of three rows 1024 pixels long.
 __host__ __device__ inline int plane_hb(int H) { return (H + 31) >> 5; }
+#ifdef __HIPCC__
+// Row of raster position pos = y * W + x without a division: with m = ceil(2^36 / W) = (2^36 + e) / W, e < W < 2^12,
+// pos * m / 2^36 exceeds pos / W by pos * e / (W * 2^36) < 1 / W for pos < 2^24 (frames are at most 4095 a side).
+__device__ __forceinline__ int row_of(const DetCfg& cfg, uint32_t pos) { return (int)(__umulhi(pos, cfg.magicW) >> 4); }
+#endif
 __host__ __device__ inline size_t plane_words(int H, int WS) { return (size_t)plane_hb(H) * WS * 32; }
 __host__ __device__ inline size_t plane_word_index(int WS, int xw, int y) {
     return ((size_t)(y >> 5) * WS + xw) * 32 + (y & 31);

@@ -88,8 +88,9 @@ __device__ __forceinline__ uint32_t seed_columns(int bx, uint32_t north, uint32_
 __host__ __device__ __forceinline__ size_t seed_table_size(int H, int W) {
     return (size_t)(H / (kSeedGrid / 2) + 1) * W + (size_t)(W / (kSeedGrid / 2) + 1) * H;
 }
-__device__ __forceinline__ size_t seed_table_index(int H, int W, uint32_t pos) {
-    const int y = (int)(pos / (uint32_t)W), x = (int)(pos - (uint32_t)y * (uint32_t)W);
+__device__ __forceinline__ size_t seed_table_index(const DetCfg& cfg, uint32_t pos) {
+    const int H = cfg.H, W = cfg.W;
+    const int y = row_of(cfg, pos), x = (int)(pos - (uint32_t)y * (uint32_t)W);
     constexpr int G2 = kSeedGrid / 2;
     if ((y & (G2 - 1)) == 0) return (size_t)(y / G2) * W + x;
     return (size_t)(H / G2 + 1) * W + (size_t)(x / G2) * H + y;
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(64) void k_contour_starts(const uint32_t* __restric
             for (unsigned int k = lane; k < fit; k += 64) {
                 const uint64_t v = seedStage[k];
                 seeds[g + k] = v;
-                myTable[seed_table_index(H, W, (uint32_t)(v & 0xFFFFFFFFull))] = g + k;
+                myTable[seed_table_index(cfg, (uint32_t)(v & 0xFFFFFFFFull))] = g + k;
             }
             seedStaged = 0;
         }
@@ -416,36 +417,40 @@ constexpr int kTileWords = kWinRows * 2 * 64;  // LDS words per wavefront
 
 struct TileWin {
     int gx, gy;  // window origin in pieces: columns [32 gx, 32 gx + 64), rows [gy << kPL, (gy + 2) << kPL)
-    bool valid;
 
+    // no window loaded yet: an origin so far out that nothing is covered and every piece of the next move is new
+    __device__ __forceinline__ void invalidate() { gx = -(1 << 20); gy = 0; }
     // the 3x3 neighbourhood of (x, y) lies inside the window
     __device__ __forceinline__ bool covers(int x, int y) const {
-        return valid && (unsigned)(x - (gx << 5) - 1) < 62u && (unsigned)(y - (gy << kPL) - 1) < (unsigned)(kWinRows - 2);
+        return (unsigned)(x - gx * 32 - 1) < 62u && (unsigned)(y - gy * kPieceRows - 1) < (unsigned)(kWinRows - 2);
     }
     // close to leaving the window (never true right after recentre(), which leaves >= 16 columns and
     // kPieceRows / 2 rows of margin)
     __device__ __forceinline__ bool near_edge(int x, int y) const {
         constexpr int my = kPieceRows / 2 - 1;  // row margin that triggers a move along with the others
-        return !(valid && (unsigned)(x - (gx << 5) - 12) < 40u && (unsigned)(y - (gy << kPL) - my) < (unsigned)(kWinRows - 2 * my));
+        return !((unsigned)(x - gx * 32 - 12) < 40u && (unsigned)(y - gy * kPieceRows - my) < (unsigned)(kWinRows - 2 * my));
     }
     // tile word index: (row * 64 + lane) * 2 + column, i.e. one 64-bit read fetches both words of a row.
     // All the loads of a move are issued before the first LDS write: one memory latency per move instead of one
-    // per piece.
+    // per piece.  Pieces beyond the plane are loaded from the nearest piece inside it instead of being zeroed: they
+    // are never looked at, because the bit planes carry a zero frame one pixel wide (k_gray_thresh3), so a border
+    // pixel has 1 <= x <= W - 2 and 1 <= y <= H - 2 and its neighbourhood lies inside the image.  A move costs the
+    // whole wave its instructions whenever one lane needs it, which is at almost every opportunity: it is kept lean.
     __device__ __forceinline__ void recentre(const uint32_t* __restrict__ plane, int WS, int H, int x, int y,
                                                      uint32_t* __restrict__ tile, int lane) {
         const int ngx = (x - 16) >> 5, ngy = (y - kPieceRows / 2) >> kPL;
         const int pieceRows = plane_hb(H) << (5 - kPL);
+        const int dx = ngx - gx, dy = ngy - gy;  // piece (ngx + i, ngy + j) is in the old window iff dx + i and dy + j are 0 or 1
         uint4 v[4][kPieceRows / 4];
         bool fresh[4];
 #pragma unroll
         for (int p = 0; p < 4; p++) {
-            const int hx = ngx + (p & 1), hy = ngy + (p >> 1);
-            fresh[p] = !(valid && hx >= gx && hx <= gx + 1 && hy >= gy && hy <= gy + 1);
-#pragma unroll
-            for (int q = 0; q < kPieceRows / 4; q++) v[p][q] = make_uint4(0, 0, 0, 0);
-            if (fresh[p] && hx >= 0 && hx < WS && hy >= 0 && hy < pieceRows) {
+            const int i = p & 1, j = p >> 1;
+            fresh[p] = (unsigned)(dx + i) > 1u || (unsigned)(dy + j) > 1u;
+            if (fresh[p]) {
+                const int hx = min(max(ngx + i, 0), WS - 1), hy = min(max(ngy + j, 0), pieceRows - 1);
                 const uint4* src = reinterpret_cast<const uint4*>(
-                    plane + ((size_t)(hy >> (5 - kPL)) * WS + hx) * 32 + (hy & ((32 >> kPL) - 1)) * kPieceRows);
+                    plane + (unsigned)(((hy >> (5 - kPL)) * WS + hx) * 32 + (hy & ((32 >> kPL) - 1)) * kPieceRows));
 #pragma unroll
                 for (int q = 0; q < kPieceRows / 4; q++) v[p][q] = src[q];
             }
@@ -465,7 +470,6 @@ struct TileWin {
         }
         gx = ngx;
         gy = ngy;
-        valid = true;
     }
     __device__ __forceinline__ uint32_t mask(const uint32_t* __restrict__ tile, int lane, int x, int y) const {
         const uint2* t2 = reinterpret_cast<const uint2*>(tile) + lane;
@@ -674,7 +678,7 @@ __global__ __launch_bounds__(256) void k_trace_short(const uint32_t* __restrict_
                         const uint32_t pos = (uint32_t)(c & 0xFFFFFFFFull);
                         plane = planes + ((size_t)(uint32_t)(c >> 40) * S + (int)((c >> 36) & 7u)) * perPlane;
                         isHole = (c >> 39) & 1u;
-                        const int x0 = (int)(pos % W), y0 = (int)(pos / W);
+                        const int y0 = row_of(cfg, pos), x0 = (int)pos - y0 * W;
                         startKey = y0 * W + x0;
                         count = 0;
                         active = true;
@@ -829,8 +833,7 @@ __device__ __forceinline__ void seg_walk_items(const uint32_t* __restrict__ plan
     int startKey = 0, cx = 1, cy = 1, s = 0;
     const uint32_t* plane = planes;
     TileWin win;
-    win.gx = win.gy = 0;
-    win.valid = false;
+    win.invalidate();
     WaveQueue queue;
     queue.start(wave, nWaves, nMine, kWalkBatch);
 
@@ -894,8 +897,8 @@ __device__ __forceinline__ void seg_walk_items(const uint32_t* __restrict__ plan
                 nextI = ~0u;
                 const uint32_t pos = (uint32_t)(c & 0xFFFFFFFFull);
                 plane = planes + ((size_t)(uint32_t)(c >> 40) * S + (int)((c >> 36) & 7u)) * perPlane;
-                cx = (int)(pos % W);
-                cy = (int)(pos / W);
+                cy = row_of(cfg, pos);
+                cx = (int)pos - cy * W;
                 isHole = isCand & (int)((c >> 39) & 1u);
                 startKey = cy * W + cx;
                 minAll = minEast = 0xFFFFFFFFu;
@@ -908,7 +911,7 @@ __device__ __forceinline__ void seg_walk_items(const uint32_t* __restrict__ plan
                 total = 0;
                 startPix = (uint32_t)cx | ((uint32_t)cy << 16);
                 chAcc = 0;
-                win.valid = false;
+                win.invalidate();
                 st = 1;
                 fresh = isCand;
             }
@@ -988,8 +991,9 @@ __global__ __launch_bounds__(64) void k_seg_walk(const uint32_t* __restrict__ pl
 
 // Turn "goes on at the seed at (plane, position)" into that seed's id: one lane per record.
 __global__ __launch_bounds__(256) void k_seg_link(SegRec* __restrict__ seg, unsigned int segCap, unsigned int seedCap,
-                                                  unsigned int candCap, int S, int H, int W, const uint64_t* __restrict__ seeds,
+                                                  unsigned int candCap, DetCfg cfg, const uint64_t* __restrict__ seeds,
                                                   const uint32_t* __restrict__ seedTable, Counters* __restrict__ ctr) {
+    const int S = cfg.nScales, H = cfg.H, W = cfg.W;
     const unsigned int nSeeds = min(ctr->nSeeds, seedCap), nLong = min(ctr->nLong, candCap);
     const unsigned int nItems = min(nSeeds + nLong, segCap);
     const unsigned int nVirt = min(ctr->nVirt, segCap - nItems);
@@ -998,7 +1002,7 @@ __global__ __launch_bounds__(256) void k_seg_link(SegRec* __restrict__ seg, unsi
         const unsigned int id = t < nItems ? t : segCap - 1u - (t - nItems);
         if (seg[id].next != kSegPending) continue;
         const uint32_t pos = seg[id].pad0, fs = seg[id].pad1;  // position; frame << 4 | hole << 3 | scale
-        uint32_t v = seedTable[((size_t)(fs >> 4) * S + (fs & 7u)) * perPlane + seed_table_index(H, W, pos)];
+        uint32_t v = seedTable[((size_t)(fs >> 4) * S + (fs & 7u)) * perPlane + seed_table_index(cfg, pos)];
         // the entry is this call's only if the seed list agrees (the table is never cleared)
         if (v >= nSeeds || seeds[v] != pack_cand(fs >> 4, 0u, fs & 7u, pos)) {
             v = kSegNone;
@@ -1203,8 +1207,7 @@ __global__ __launch_bounds__(64) void k_trace_store(const uint32_t* __restrict__
     uint32_t oidx = 0, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // pool index of the next point; points not yet written
     const uint32_t* plane = planes;
     TileWin win;
-    win.gx = win.gy = 0;
-    win.valid = false;
+    win.invalidate();
     WaveQueue queue;
     queue.start(blockIdx.x, gridDim.x, n, kStoreBatch);
 
@@ -1222,7 +1225,7 @@ __global__ __launch_bounds__(64) void k_trace_store(const uint32_t* __restrict__
                     left = (int)k.count;
                     oidx = k.dst;
                     nq = 0;
-                    win.valid = false;
+                    win.invalidate();
                     active = left > 0 && left <= kCkStride && k.dst < poolCap && k.count <= poolCap - k.dst;  // (empty or not a task: skipped)
                 } else if (queue.empty()) {
                     exhausted = true;
@@ -1395,7 +1398,7 @@ void launch_trace(const DetCfg& c, const DetBuffers& b, hipStream_t st) {
     hipLaunchKernelGGL(k_seg_walk, dim3(kTraceWaves), dim3(64), 0, st, b.planes, c, b.seeds, b.seedCap, b.candLong, b.candCap, b.seg,
                        b.segCap, b.chain, b.counters);
     debug_stage(st, "seg_walk");
-    hipLaunchKernelGGL(k_seg_link, dim3(256 * 8), dim3(256), 0, st, b.seg, b.segCap, b.seedCap, b.candCap, c.nScales, c.H, c.W,
+    hipLaunchKernelGGL(k_seg_link, dim3(256 * 8), dim3(256), 0, st, b.seg, b.segCap, b.seedCap, b.candCap, c,
                        b.seeds, b.seedTable, b.counters);
     debug_stage(st, "seg_link");
     hipLaunchKernelGGL(k_resolve, dim3(b.resolveWaves), dim3(64), 0, st, c, b.candLong, b.candCap, b.seedCap, b.seg, b.segCap, b.contours,
