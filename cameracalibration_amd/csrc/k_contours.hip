@@ -782,8 +782,13 @@ __global__ __launch_bounds__(256) void k_trace_short(const uint32_t* __restrict_
 // Rows 0 / G/2 (mod G) carry west / east seeds, the other rows north / south seeds at columns 0 / G/2 (mod G);
 // -1: the pixel cannot be a seed.  The start pass applies the same rule word-wide (seed_columns).
 __device__ __forceinline__ int seed_dir(int x, int y) {
-    const int ym = y & (kSeedGrid - 1), xm = x & (kSeedGrid - 1);
-    return ym == 0 ? 4 : ym == kSeedGrid / 2 ? 0 : xm == 0 ? 2 : xm == kSeedGrid / 2 ? 6 : -1;
+    // (selects only: as nested conditions this compiled to branches inside the walkers' step)
+    constexpr int G2 = kSeedGrid / 2;
+    static_assert(kSeedGrid == 64, "the shifts below assume a 64-pixel grid: bit 5 of a coordinate tells the two kinds of line apart");
+    const int onRow = (y & (G2 - 1)) == 0, onCol = (x & (G2 - 1)) == 0;
+    const int dRow = 4 ^ ((y >> 3) & 4);      // row 0 (mod 64): 4 (west), row 32: 0 (east)
+    const int dCol = 2 + ((x >> 3) & 4);      // column 0 (mod 64): 2 (north), column 32: 6 (south)
+    return onRow ? dRow : onCol ? dCol : -1;
 }
 // ... and the border must go on on both sides of the crack (m = neighbour mask, bit d = direction d)
 __device__ __forceinline__ bool seed_supported(uint32_t m, int dir) {
@@ -841,7 +846,10 @@ __device__ __forceinline__ void seg_walk_items(const uint32_t* __restrict__ plan
     // work item, moving a lane's window -- happens in a service phase every kService steps, for all lanes that need
     // it at once: between two phases the wave runs kService lean steps (LDS and registers only).  A window is moved
     // when its lane is within kService + 1 pixels of leaving it, so no lane can run out of window between phases.
-    constexpr int kService = kPieceRows / 2 - 2 > 1 ? kPieceRows / 2 - 2 : 1;
+#ifndef KSERVICE
+#define KSERVICE 4
+#endif
+    constexpr int kService = KSERVICE;
     for (unsigned int iter = 0;; iter++) {
         if (iter % kService == 0) {
             // ---- finished segments: record, continuation ----
