@@ -57,6 +57,14 @@ __device__ __forceinline__ uint32_t fill_down(uint32_t seed, uint32_t run) {
     return __brev((((r + s) ^ r) & r) | s);
 }
 
+// A wavefront's LDS operations execute in order: lanes of one wavefront exchange data through LDS without s_barrier,
+// only the compiler must keep the order.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 constexpr int kStage = 512;  // starts staged per wavefront before a flush
 constexpr int kSeedStage = 256;  // border seeds likewise
 
@@ -312,27 +320,33 @@ __device__ __forceinline__ uint32_t pack_mask(uint32_t t, uint32_t m, uint32_t u
            ((u & 1u) << 5) | (((u >> 1) & 1u) << 6) | (((u >> 2) & 1u) << 7);
 }
 
-// (x,y) is an interior pixel; the planes have a zero frame.
+// (x,y) is an interior pixel; the planes have a zero frame.  The three rows are neighbours in one plane block unless
+// y is the block's first or last row; offsets are 32-bit words from the plane's base.
 __device__ __forceinline__ uint32_t nb_mask(const uint32_t* __restrict__ plane, int WS, int x, int y) {
-    const int wi = (x - 1) >> 5, sh = (x - 1) & 31;
-    const size_t i0 = plane_word_index(WS, wi, y - 1), i1 = plane_word_index(WS, wi, y), i2 = plane_word_index(WS, wi, y + 1);
-    uint64_t a = plane[i0], b = plane[i1], c = plane[i2];
+    const int xm = x - 1, wi = xm >> 5, sh = xm & 31, yr = y & 31;
+    const uint32_t blockRow = (uint32_t)WS * 32u;
+    const uint32_t i1 = ((uint32_t)(y >> 5) * (uint32_t)WS + (uint32_t)wi) * 32u + (uint32_t)yr;
+    const uint32_t i0 = yr == 0 ? i1 - blockRow + 31u : i1 - 1u, i2 = yr == 31 ? i1 + blockRow - 31u : i1 + 1u;
+    const uint32_t a = plane[i0], b = plane[i1], c = plane[i2];
+    uint32_t a2 = 0, b2 = 0, c2 = 0;
     if (sh > 29) {  // the field straddles two words: same row of the next block
-        a |= (uint64_t)plane[i0 + 32] << 32;
-        b |= (uint64_t)plane[i1 + 32] << 32;
-        c |= (uint64_t)plane[i2 + 32] << 32;
+        a2 = plane[i0 + 32];
+        b2 = plane[i1 + 32];
+        c2 = plane[i2 + 32];
     }
-    return pack_mask((uint32_t)(a >> sh) & 7u, (uint32_t)(b >> sh) & 7u, (uint32_t)(c >> sh) & 7u);
+    return pack_mask(__funnelshift_r(a, a2, sh) & 7u, __funnelshift_r(b, b2, sh) & 7u, __funnelshift_r(c, c2, sh) & 7u);
 }
 
 // the same mask in the direction numbering of the vertically mirrored image (d -> (8 - d) & 7)
 __device__ __forceinline__ uint32_t flip_mask(uint32_t m) {
-    return (m & 0x11u) | ((m & 0x02u) << 6) | ((m & 0x80u) >> 6) | ((m & 0x04u) << 4) | ((m & 0x40u) >> 4) |
-           ((m & 0x08u) << 2) | ((m & 0x20u) >> 2);
+    // bit d -> bit (8 - d) & 7: the byte reversed (d -> 7 - d) and rotated up by one
+    const uint32_t r = __brev(m) >> 24;
+    return ((r | (r << 8)) >> 7) & 0xFFu;
 }
 
-__device__ __forceinline__ int dir_dx(int d) { return (d == 0 || d == 1 || d == 7) ? 1 : (d >= 3 && d <= 5) ? -1 : 0; }
-__device__ __forceinline__ int dir_dy(int d) { return (d >= 1 && d <= 3) ? -1 : (d >= 5 && d <= 7) ? 1 : 0; }
+// direction -> step, two bits per direction holding d + 1
+__device__ __forceinline__ int dir_dx(int d) { return (int)((0x901Au >> (2 * d)) & 3u) - 1; }
+__device__ __forceinline__ int dir_dy(int d) { return (int)((0xA901u >> (2 * d)) & 3u) - 1; }
 
 // One border follower with OpenCV's icvFetchContour stepping rule.  FLIP runs the rule on the vertically
 // mirrored image, which walks the same border in the opposite sense; it is only used to look for an earlier
@@ -486,9 +500,6 @@ struct TileWin {
     }
 };
 
-// direction -> step, two bits per direction holding d + 1
-__device__ __forceinline__ int fast_dx(int d) { return (int)((0x901Au >> (2 * d)) & 3u) - 1; }
-__device__ __forceinline__ int fast_dy(int d) { return (int)((0xA901u >> (2 * d)) & 3u) - 1; }
 
 // the initial clockwise search of a fresh start (s_end - 1, s_end - 2, ...): direction of the neighbour the
 // border closes through, or -1 for a single pixel.  Rotated so that bit j is direction s_end + j, the first
@@ -522,6 +533,15 @@ struct WaveQueue {
         hi = b + batch < n ? b + batch : n;
         if (base >= n) drained = true;
     }
+    // draw the next batch from the shared counter (uniform call)
+    __device__ __forceinline__ void refill(unsigned int* head, unsigned int n, unsigned int batch, int lane) {
+        unsigned int b = 0;
+        if (lane == 0) b = atomicAdd(head, batch);
+        b = __builtin_amdgcn_readfirstlane(b) + base;
+        lo = b < n ? b : n;
+        hi = b + batch < n ? b + batch : n;
+        if (b + batch >= n) drained = true;
+    }
     // every lane calls this; returns the item index for lanes with want == true (rank order) or ~0u if none is left
     // for them right now.  `unit` lanes form one consumer (pairs: unit = 2, the even lane's want counts).
     template <int UNIT>
@@ -529,14 +549,7 @@ struct WaveQueue {
         unsigned long long bal = __ballot(want);
         if (UNIT == 2) bal &= 0x5555555555555555ull;
         if (!bal) return ~0u;
-        if (lo == hi && !drained) {
-            unsigned int b = 0;
-            if (lane == 0) b = atomicAdd(head, batch);
-            b = __builtin_amdgcn_readfirstlane(b) + base;
-            lo = b < n ? b : n;
-            hi = b + batch < n ? b + batch : n;
-            if (b + batch >= n) drained = true;
-        }
+        if (lo == hi && !drained) refill(head, n, batch, lane);
         const unsigned int rank = (unsigned int)__popcll(bal & ((1ull << (lane & ~(UNIT - 1))) - 1ull));
         const unsigned int avail = hi - lo, cnt = (unsigned int)__popcll(bal);
         const unsigned int idx = (want && rank < avail) ? lo + rank : ~0u;
@@ -633,8 +646,10 @@ __global__ __launch_bounds__(256) void k_trace_short(const uint32_t* __restrict_
                                                      unsigned int contourCap, unsigned int poolCap,
                                                      StoreTask* __restrict__ tasks, unsigned int taskCap, Counters* __restrict__ ctr) {
     __shared__ uint64_t s_long[4][kLongStage];
+    __shared__ uint64_t s_batch[4][kShortBatch];
     const int lane = threadIdx.x & 63;
     uint64_t* const stage = s_long[threadIdx.x >> 6];
+    uint64_t* const batch = s_batch[threadIdx.x >> 6];
     unsigned int staged = 0;  // uniform
     const unsigned int n = min(ctr->nCand, candCap);
     const int H = cfg.H, W = cfg.W, WS = cfg.WS, S = cfg.nScales;
@@ -655,6 +670,15 @@ __global__ __launch_bounds__(256) void k_trace_short(const uint32_t* __restrict_
 
     WaveQueue queue;
     queue.start(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), gridDim.x * (blockDim.x >> 6), n, kShortBatch);
+    // The wave's batch of candidates is read into LDS in one coalesced sweep when the batch is drawn: a lane that takes
+    // up a candidate then has it after an LDS read instead of a trip to memory that the whole wave waits for.
+    unsigned int batchLo = queue.lo;
+    auto load_batch = [&]() {
+        batchLo = queue.lo;
+        for (unsigned int k = lane; k < queue.hi - queue.lo; k += 64) batch[k] = cand[queue.lo + k];
+        wave_lds_sync();
+    };
+    load_batch();
     WaveAlloc poolA, slotA, taskA;
     bool active = false, exhausted = false, isHole = false, bwActive = false;
     uint64_t c = 0;
@@ -670,10 +694,14 @@ __global__ __launch_bounds__(256) void k_trace_short(const uint32_t* __restrict_
         int res = -2;
         {
             const bool need = !active && !exhausted;
+            if (queue.lo == queue.hi && !queue.drained && __any(need)) {
+                queue.refill(&ctr->qShort, n, kShortBatch, lane);
+                load_batch();
+            }
             const unsigned int i = queue.pop<1>(need, &ctr->qShort, n, kShortBatch, lane);
             if (need) {
                 if (i != ~0u) {
-                    c = cand[i];
+                    c = batch[i - batchLo];
                     if (c != ~0ull) {  // ~0 would mark a slot that was never filled
                         const uint32_t pos = (uint32_t)(c & 0xFFFFFFFFull);
                         plane = planes + ((size_t)(uint32_t)(c >> 40) * S + (int)((c >> 36) & 7u)) * perPlane;
@@ -968,8 +996,8 @@ __device__ __forceinline__ void seg_walk_items(const uint32_t* __restrict__ plan
             }
             count += (uint32_t)emit;
             total += (uint32_t)emit;
-            cx += emit ? fast_dx(q) : 0;
-            cy += emit ? fast_dy(q) : 0;
+            cx += emit ? dir_dx(q) : 0;
+            cy += emit ? dir_dy(q) : 0;
             s = emit ? (q ^ 4) : s;
             const int closed = emit & isCand & (pack_state(cx, cy, s) == state0 ? 1 : 0);  // a border without seeds closed
             const int tooLong = emit & isCand & (total > (uint32_t)cfg.maxPerim ? 1 : 0) & (closed ^ 1);
@@ -1279,8 +1307,8 @@ __global__ __launch_bounds__(64) void k_trace_store(const uint32_t* __restrict__
             } else {
                 const uint32_t rot = ((m >> (s + 1)) | (m << (7 - s))) & 0xFFu;
                 const int d = (s + __ffs(rot)) & 7;
-                cx += fast_dx(d);
-                cy += fast_dy(d);
+                cx += dir_dx(d);
+                cy += dir_dy(d);
                 s = d ^ 4;
             }
         }
@@ -1316,7 +1344,7 @@ __device__ __forceinline__ void copy_short_task(const uint32_t* __restrict__ cha
         if ((unsigned int)(32 * m) >= cnt) break;  // (the same for all lanes of the half-wave)
         const unsigned int j = (unsigned int)(32 * m + l32);
         const int q = (int)((w[m] >> (4 * (j & 7u))) & 7u);
-        const int dx = fast_dx(q), dy = fast_dy(q);
+        const int dx = dir_dx(q), dy = dir_dy(q);
         // both sums in one word: every lane's step is biased by 1 so that the fields never go negative
         const uint32_t inc = half_wave_scan((uint32_t)(dx + 1) | ((uint32_t)(dy + 1) << 16));
         const int sx = (int)(inc & 0xFFFFu) - (l32 + 1), sy = (int)(inc >> 16) - (l32 + 1);  // steps 32 m .. j summed
@@ -1356,8 +1384,8 @@ __global__ __launch_bounds__(256) void k_trace_copy(const uint32_t* __restrict__
             ox[m] = x;
             oy[m] = y;
             const int q = (int)((d >> (4 * m)) & 7u);
-            x += fast_dx(q);
-            y += fast_dy(q);
+            x += dir_dx(q);
+            y += dir_dy(q);
         }
         // inclusive prefix sums of the lanes' totals within the half-wave (both in one word, biased by 8 per lane)
         const uint32_t inc = half_wave_scan((uint32_t)(x + 8) | ((uint32_t)(y + 8) << 16));
@@ -1384,13 +1412,17 @@ __global__ __launch_bounds__(256) void k_trace_copy(const uint32_t* __restrict__
 }  // namespace
 
 void launch_contour_starts(const DetCfg& c, const DetBuffers& b, int B, hipStream_t st) {
-    // one wavefront per (plane, group of 62 block columns, band of rows); bands of a plane only when there are too
-    // few planes to fill the chip (each band re-reads one row), in whole groups of eight rows
+    // one wavefront per (plane, group of 62 block columns, band of rows); a plane is cut into bands (each re-reads one
+    // row; whole groups of eight rows) when there are too few planes to fill the chip, and into three for large batches
     const int colGroups = (c.WS + kStartCols - 1) / kStartCols;
     const long long waves = (long long)B * c.nScales * colGroups;
     const int totalGroups = plane_hb(c.H) * 4;
     int bands = 1;
     if (waves < 256 * 16) bands = (int)std::min<long long>((256 * 16 + waves - 1) / waves, (totalGroups + 3) / 4);
+    // a wavefront that takes a whole plane runs long, and the chip holds ~26 of them per CU: with one or two rounds of
+    // such wavefronts the last ones run on a half-empty chip (12288 planes: 2.08 ms in one band, 1.70 ms in three; more
+    // bands than needed cost an atomic per list and wavefront on two shared counters: 2.6 ms with eighteen)
+    if (waves >= 256 * 8) bands = std::max(bands, 3);
     const int bandGroups = (totalGroups + bands - 1) / bands;
     bands = (totalGroups + bandGroups - 1) / bandGroups;
     const long long grid = waves * bands;

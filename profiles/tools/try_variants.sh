@@ -6,7 +6,7 @@ lib=cameracalibration_amd/libcamsync_hip.so
 cp $lib /tmp/lib_orig.so
 for v in variants/*.so; do
   cp "$v" $lib
-  timeout -k 10 120 python3 bench.py --no-cpu --calib-views 0 --steps 3 --warmup 1 > /tmp/b.json
+  timeout -k 10 120 python3 bench.py --no-cpu --calib-views 0 --steps 3 --warmup 1 $BENCH_ARGS > /tmp/b.json
   python3 -c "
 import json,sys;d=json.load(open('/tmp/b.json'));s=d['stage_ms_per_step'];print('$v', round(d['value']), 'starts', s['contour_starts'], 'trace', s['trace'], 'poses', d['check']['frames_with_pose'], d['check']['mean_markers_per_frame'])"
 done
