@@ -79,7 +79,9 @@ __device__ __forceinline__ uint32_t pw_at(const uint32_t* __restrict__ plane, in
 // plane.  The rows above and below a row are then the lane's own registers from the previous / next step, and only
 // the one bit that crosses a word boundary comes from the neighbouring lane (DPP wave shifts): about twenty vector
 // instructions per 32 pixels when nothing starts in them.  Two groups of rows are loaded ahead of the one being
-// processed.  Starts are staged in LDS and appended to the global list with one atomic per flush.
+// processed.  (A block's 128-byte line is touched in four rounds, microseconds apart, and the chip's wavefronts hold
+// more lines in flight than the L2 keeps: FETCH_SIZE shows 2.6 x the planes.  A variant whose lanes pair up to read
+// whole lines fetched 1.1 x and was 5 % slower: the pass is bound by instruction issue, not by that traffic.)  Starts are staged in LDS and appended to the global list with one atomic per flush.
 // Seed grid pitch G (a power of two, >= 32): the pixels of word bx (32 pixels) that lie on a north-seed column
 // (x = 0 mod G, where `north` must hold) or a south-seed column (x = G/2 mod G, where `south` must hold).
 constexpr int kSeedGrid = 64;
@@ -680,19 +682,22 @@ __global__ __launch_bounds__(256) void k_trace_short(const uint32_t* __restrict_
     };
     load_batch();
     WaveAlloc poolA, slotA, taskA;
-    bool active = false, exhausted = false, isHole = false, bwActive = false;
+    bool active = false, exhausted = false, isHole = false, bwActive = false, fresh = false;
     uint64_t c = 0;
     int count = 0, startKey = 0;
     const uint32_t* plane = planes;
-    Tracer<false> fw;
-    Tracer<true> bw;
-    fw.x0 = fw.y0 = fw.x1 = fw.y1 = fw.cx = fw.cy = 1; fw.s = 0; fw.m = 0;
-    bw.x0 = bw.y0 = bw.x1 = bw.y1 = bw.cx = bw.cy = 1; bw.s = 0; bw.m = 0;
+    // the candidate's start pixel; per follower (f forwards, b the other way round, on the vertically mirrored image):
+    // the second pixel, the current pixel and the direction to the predecessor
+    int x0 = 1, y0 = 1, fx1 = 1, fy1 = 1, fcx = 1, fcy = 1, fs = 0, bx1 = 1, by1 = 1, bcx = 1, bcy = 1, bs = 0;
 
-    for (;;) {
-        // res: -2 keep going, -1 budget exhausted (long list), 0 drop, > 0 closed with that many points
-        int res = -2;
-        {
+    // Taking up candidates is the expensive part of an iteration for what it does (a seventh of the lanes finish in
+    // any one iteration, and the whole wave pays for their set-up), so it happens every kPick-th iteration only and
+    // is kept to decoding the candidate: a fresh lane's followers get their start state in the step phase, from the
+    // neighbour mask that every active lane fetches at the top of an iteration anyway.
+    constexpr unsigned int kPick = 3;
+    bool anyActive = false;  // uniform
+    for (unsigned int iter = 0;; iter++) {
+        if (iter % kPick == 0 || !anyActive) {
             const bool need = !active && !exhausted;
             if (queue.lo == queue.hi && !queue.drained && __any(need)) {
                 queue.refill(&ctr->qShort, n, kShortBatch, lane);
@@ -706,37 +711,75 @@ __global__ __launch_bounds__(256) void k_trace_short(const uint32_t* __restrict_
                         const uint32_t pos = (uint32_t)(c & 0xFFFFFFFFull);
                         plane = planes + ((size_t)(uint32_t)(c >> 40) * S + (int)((c >> 36) & 7u)) * perPlane;
                         isHole = (c >> 39) & 1u;
-                        const int y0 = row_of(cfg, pos), x0 = (int)pos - y0 * W;
-                        startKey = y0 * W + x0;
+                        y0 = row_of(cfg, pos);
+                        x0 = (int)pos - y0 * W;
+                        fcx = bcx = x0;
+                        fcy = bcy = y0;
+                        startKey = (int)pos;
                         count = 0;
-                        active = true;
-                        const uint32_t raw = nb_mask(plane, WS, x0, y0);
-                        if (!fw.init(raw, x0, y0, isHole)) res = 1;  // a single pixel
-                        else bwActive = bw.init(raw, x0, y0, isHole);
+                        active = fresh = bwActive = true;
                     }
                 } else if (queue.empty()) {
                     exhausted = true;
                 }
             }
         }
-        if (!__any(active)) {
+        anyActive = __any(active);
+        if (!anyActive) {
             if (__all(exhausted)) break;
             continue;
         }
+        // neighbour masks at the followers' pixels (a fresh lane's two followers stand on the start pixel)
+        uint32_t mf = 0, mb = 0;
+        if (active) {
+            mf = nb_mask(plane, WS, fcx, fcy);
+            if (bwActive) mb = flip_mask(nb_mask(plane, WS, bcx, bcy));
+        }
+        // res: -2 keep going, -1 budget exhausted (long list), 0 drop, > 0 closed with that many points
+        int res = -2;
+        if (active && fresh) {
+            // start states (icvFetchContour): the first step goes to the first foreground neighbour clockwise from
+            // s_end - 1; bit j of r = direction s_end + 1 + j, so that neighbour is the highest set bit of bits 0..6
+            const int s_end = isHole ? 0 : 4, b = (s_end + 1) & 7;
+            const uint32_t rf = ((mf >> b) | (mf << (8 - b))) & 0x7Fu, rb = ((mb >> b) | (mb << (8 - b))) & 0x7Fu;
+            const bool found = rf != 0;  // (and then rb != 0: the same neighbours, mirrored)
+            fs = found ? (s_end + 1 + (31 - __clz(rf))) & 7 : s_end;
+            bs = found ? (s_end + 1 + (31 - __clz(rb))) & 7 : s_end;
+            fx1 = x0 + dir_dx(fs);
+            fy1 = y0 + dir_dy(fs);
+            bx1 = x0 + dir_dx(bs);
+            by1 = y0 - dir_dy(bs);
+            bwActive = found;
+            fresh = false;
+            if (!found) res = 1;  // a single pixel
+        }
         if (active && res == -2) {
-            int px, py;
-            bool east;
-            const bool closed = fw.step(plane, WS, px, py, east);
-            if ((!isHole || east) && py * W + px < startKey) {
+            // one step forwards: sweep counter-clockwise from fs + 1 (mf always holds the neighbour we came from)
+            const uint32_t rot = ((mf >> (fs + 1)) | (mf << (7 - fs))) & 0xFFu;
+            const int k = __ffs(rot), d = (fs + k) & 7;
+            const bool east = fs + k >= 9;  // the east crack of the pixel being left is on this border
+            const int key = fcy * W + fcx, nx = fcx + dir_dx(d), ny = fcy + dir_dy(d);
+            const bool closed = nx == x0 && ny == y0 && fcx == fx1 && fcy == fy1;
+            fcx = nx;
+            fcy = ny;
+            fs = d ^ 4;
+            if ((!isHole || east) && key < startKey) {
                 res = 0;
             } else {
                 count++;
                 if (closed) res = count;
                 else if (count >= kShortBudget) res = -1;
                 else if (bwActive) {
-                    const bool bclosed = bw.step(plane, WS, px, py, east);
-                    if ((!isHole || east) && py * W + px < startKey) res = 0;
-                    if (bclosed) bwActive = false;
+                    // ... and one the other way round, on the mirrored image (rows run upwards)
+                    const uint32_t brot = ((mb >> (bs + 1)) | (mb << (7 - bs))) & 0xFFu;
+                    const int bk = __ffs(brot), bd = (bs + bk) & 7;
+                    const bool beast = bs + bk >= 9;
+                    const int bkey = bcy * W + bcx, bnx = bcx + dir_dx(bd), bny = bcy - dir_dy(bd);
+                    if (bnx == x0 && bny == y0 && bcx == bx1 && bcy == by1) bwActive = false;
+                    bcx = bnx;
+                    bcy = bny;
+                    bs = bd ^ 4;
+                    if ((!isHole || beast) && bkey < startKey) res = 0;
                 }
             }
         }
@@ -874,10 +917,7 @@ __device__ __forceinline__ void seg_walk_items(const uint32_t* __restrict__ plan
     // work item, moving a lane's window -- happens in a service phase every kService steps, for all lanes that need
     // it at once: between two phases the wave runs kService lean steps (LDS and registers only).  A window is moved
     // when its lane is within kService + 1 pixels of leaving it, so no lane can run out of window between phases.
-#ifndef KSERVICE
-#define KSERVICE 4
-#endif
-    constexpr int kService = KSERVICE;
+    constexpr int kService = 4;
     for (unsigned int iter = 0;; iter++) {
         if (iter % kService == 0) {
             // ---- finished segments: record, continuation ----

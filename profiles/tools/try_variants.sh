@@ -8,6 +8,6 @@ for v in variants/*.so; do
   cp "$v" $lib
   timeout -k 10 120 python3 bench.py --no-cpu --calib-views 0 --steps 3 --warmup 1 $BENCH_ARGS > /tmp/b.json
   python3 -c "
-import json,sys;d=json.load(open('/tmp/b.json'));s=d['stage_ms_per_step'];print('$v', round(d['value']), 'starts', s['contour_starts'], 'trace', s['trace'], 'poses', d['check']['frames_with_pose'], d['check']['mean_markers_per_frame'])"
+import json,sys;d=json.load(open('/tmp/b.json'));s=d['stage_ms_per_step'];print('$v', round(d['value']), 'starts', s['contour_starts'], 'trace', s['trace'], 'total', s['total'], 'poses', d['check']['frames_with_pose'], d['check']['mean_markers_per_frame'])"
 done
 cp /tmp/lib_orig.so $lib
