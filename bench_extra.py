@@ -199,6 +199,35 @@ def main():
     except Exception as e:
         out["host_frames_1920x1080"] = {"error": "%s: %s" % (type(e).__name__, e)}
 
+    # ---- frame ingest: raw YUYV 4:2:2 -> BGR on the device (camsync_ingest_yuyv) ----
+    try:
+        n, h, w = 512, 1080, 1920
+        ctx = _hip.Context(h, w, max_batch=n)
+        g = torch.Generator(device="cpu").manual_seed(3)
+        raw = torch.randint(0, 256, (n, h, w, 2), dtype=torch.uint8, generator=g)
+        d_raw = raw.to(dev)
+        d_bgr = torch.empty((n, h, w, 3), dtype=torch.uint8, device=dev)
+        pinned = _hip.PinnedFrames((n, h, w, 2))
+        pinned.array[...] = raw.numpy()
+        res = {}
+        for name, call in (("resident", lambda: ctx.ingest_yuyv(None, d_yuyv_ptr=d_raw.data_ptr(), d_bgr_ptr=d_bgr.data_ptr(), shape=(n, h, w))),
+                           ("pinned_host_to_device", lambda: ctx.ingest_yuyv(pinned.array, d_bgr_ptr=d_bgr.data_ptr()))):
+            call()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                call()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / 5
+            res[name] = {"frames_per_s": n / dt, "GB_per_s_read_plus_written": n * h * w * 5 / dt / 1e9}
+        res["note"] = ("512 raw 1920x1080 frames (2 B/px) to BGR frames on the device (3 B/px); 'resident' is the kernel alone "
+                       "(HBM-bound: 5 B/px), 'pinned_host_to_device' includes the copy of the raw frames over the host link")
+        out["ingest_yuyv_1920x1080"] = res
+        pinned.close()
+        del ctx, d_raw, d_bgr
+    except Exception as e:
+        out["ingest_yuyv_1920x1080"] = {"error": "%s: %s" % (type(e).__name__, e)}
+
     # ---- config 5: 8 cameras, one scene, processArucoFromMultipleCameras (host frames, mirror API) ----
     K, dist = _data.calibration("Logitec_robot_1920-1080_10.npz")
     for (h, w, camname, focus) in ((720, 1280, "Logitec_A", 0), (1080, 1920, "Logitec_robot", 10)):

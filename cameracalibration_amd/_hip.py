@@ -115,6 +115,7 @@ def load_library() -> C.CDLL:
         lib.camsync_corner_subpix.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, i32, i32, dbl, vp]
         lib.camsync_optimal_new_camera_matrix.argtypes = [vp, vp, i32, i32, i32, dbl, i32, i32, vp, vp]
         lib.camsync_undistort_batch.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp]
+        lib.camsync_ingest_yuyv.argtypes = [vp, vp, i32, i32, i32, i32, vp, i32]
         lib.camsync_calibrate.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp]
         lib.camsync_calibrate_dist.argtypes = [vp, vp, vp, i32, i32, C.c_int64, i32, i32, i32, i32, ALLREDUCE_FN, vp, vp,
                                                vp, vp, vp, vp, vp, vp]
@@ -428,6 +429,32 @@ class Context:
         self._check(self._lib.camsync_corner_subpix(self._h, _ptr(f), 0, B, H, W, Cn, _ptr(p), _ptr(n), N, int(win), int(max_iter),
                                                     float(eps), _ptr(out)))
         return out
+
+    # -- frame ingest ----------------------------------------------------
+    def ingest_yuyv(self, yuyv, d_yuyv_ptr=None, d_bgr_ptr=None, shape=None):
+        """Packed YUYV 4:2:2 frames (what a UVC camera delivers) -> BGR, as cv.VideoCapture.read() converts them.
+
+        yuyv: uint8 host array [B,H,W,2] (or [H,W,2]); or pass d_yuyv_ptr (raw device pointer) with shape=(B,H,W).
+        With d_bgr_ptr (raw device pointer to B*H*W*3 bytes) the frames stay on the GPU and None is returned;
+        otherwise the BGR frames come back as a host array of the input's batch shape."""
+        if d_yuyv_ptr is None:
+            src = np.ascontiguousarray(yuyv, dtype=np.uint8)
+            one = src.ndim == 3
+            f = src[None] if one else src
+            if f.ndim != 4 or f.shape[3] != 2:
+                raise ValueError("yuyv frames must be [B,H,W,2] or [H,W,2] uint8")
+            B, H, W = f.shape[:3]
+            in_ptr, in_dev = _ptr(f), 0
+        else:
+            B, H, W = shape
+            one = False
+            in_ptr, in_dev = C.c_void_p(d_yuyv_ptr), 1
+        if d_bgr_ptr is not None:
+            self._check(self._lib.camsync_ingest_yuyv(self._h, in_ptr, in_dev, B, H, W, C.c_void_p(d_bgr_ptr), 1))
+            return None
+        out = np.empty((B, H, W, 3), np.uint8)
+        self._check(self._lib.camsync_ingest_yuyv(self._h, in_ptr, in_dev, B, H, W, _ptr(out), 0))
+        return out[0] if one else out
 
     # -- undistortion --------------------------------------------------
     def undistort(self, frames, K, dist, new_K=None):

@@ -6,4 +6,4 @@ libcamsync_hip.so through `cameracalibration_amd._hip` instead.  There is no
 CPU fallback: importing works without a GPU, calling a compute function
 without the HIP library or a GPU raises.
 """
-from . import aruco, camera, position, referential, tools  # noqa: F401
+from . import aruco, camera, ingest, position, referential, tools  # noqa: F401

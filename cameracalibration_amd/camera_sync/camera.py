@@ -2,8 +2,10 @@
 
 On the hot path a Camera is the holder of the intrinsics (`mtx`, `dist`, loaded from
 calibration/<name>_<w>-<h>_<focus>.npz) and of the stateful world pose
-(`world2cam`, low-passed `world_position`).  Frame capture (cv.VideoCapture) is outside the scope of
-this package; image undistortion and the LM solve behind cv.calibrateCamera run on the GPU.
+(`world2cam`, low-passed `world_position`).  Opening camera hardware (cv.VideoCapture(deviceId)) is outside
+the scope of this package: a Camera takes a `captureStream` object instead (anything with VideoCapture's
+`read()`, e.g. `ingest.RawYUYVStream`, which converts a camera's raw YUYV frames on the GPU); image undistortion
+and the LM solve behind cv.calibrateCamera run on the GPU.
 """
 import os
 
@@ -100,17 +102,19 @@ class Camera:
         return mtx, dist
 
     # -- construction ----------------------------------------------------------------------
-    def __init__(self, name, deviceId, calibrationFolder: str = None, focus=0, resolution=(640, 480)):
+    def __init__(self, name, deviceId, calibrationFolder: str = None, focus=0, resolution=(640, 480), captureStream=None):
         if calibrationFolder is None:
             calibrationFolder = os.path.join(getBaseFolder(), "./calibration")
         if not os.path.exists(calibrationFolder):
             raise Exception("Calibration folder not found. Searched at " + calibrationFolder)
         self.calibrationFolder = calibrationFolder
         self.name = name
-        if deviceId != -1:
-            # camera.py:98-118 opens a cv.VideoCapture here
-            raise NotImplementedError("frame capture is outside this package's scope: use deviceId=-1 and pass frames in")
+        if deviceId != -1 and captureStream is None:
+            # camera.py:98-118 opens a cv.VideoCapture(deviceId) here and sets its focus and resolution
+            raise NotImplementedError("opening camera hardware is outside this package's scope: pass captureStream= "
+                                      "(e.g. ingest.RawYUYVStream) or use deviceId=-1 and pass frames in")
         self.deviceId = deviceId
+        self.captureStream = captureStream
         self.world_position = Position(0, 0, 0)
         self._focus = focus
         self._resolution = resolution
@@ -142,7 +146,13 @@ class Camera:
         print(f"Calibration file saved in {self.calibrationFilePath}")
 
     def takePic(self):
-        raise NotImplementedError("frame capture is outside this package's scope")
+        """camera.py:150-154: the next frame of the capture stream, or False when it yields none."""
+        if self.captureStream is None:
+            raise NotImplementedError("this Camera has no captureStream (opening camera hardware is outside this package's scope)")
+        ret, frame = self.captureStream.read()
+        if ret:
+            return frame
+        return ret
 
     def calibrateCamera(self, pics, pointsToFind=(7, 7)):
         """camera.py:203-222."""

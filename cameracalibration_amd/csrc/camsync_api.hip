@@ -1267,6 +1267,40 @@ int camsync_undistort_batch(camsync_ctx* c, const uint8_t* frames, int on_device
     return CAMSYNC_OK;
 }
 
+/* ---- frame ingest ---- */
+
+int camsync_ingest_yuyv(camsync_ctx* c, const uint8_t* yuyv, int in_on_device, int B, int H, int W, uint8_t* bgr, int out_on_device) {
+    if (!c) return CAMSYNC_E_ARG;
+    if (!yuyv || !bgr || B <= 0) return fail(c, CAMSYNC_E_ARG, "yuyv / bgr is NULL or batch <= 0");
+    if (H <= 0 || W <= 0 || (W % 8)) return fail(c, CAMSYNC_E_ARG, "frame width must be a positive multiple of 8 (got %dx%d)", H, W);
+    if (H > c->maxH || W > c->maxW) return fail(c, CAMSYNC_E_ARG, "frame %dx%d larger than the context's %dx%d", H, W, c->maxH, c->maxW);
+    if ((out_on_device && ((uintptr_t)bgr % 8)) || (in_on_device && ((uintptr_t)yuyv % 16)))
+        return fail(c, CAMSYNC_E_ARG, "device buffers must be aligned: yuyv to 16 bytes, bgr to 8");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t px = (size_t)H * W;
+    if (!in_on_device) {
+        int rc = ensure_staging(c);  // (maxB frames of 3 bytes a pixel: the raw frames need two)
+        if (rc) return rc;
+    }
+    if (!out_on_device && !c->d_uout) HIPCHK(c, dalloc(&c->d_uout, (size_t)c->maxB * c->maxH * c->maxW * 3));
+    // chunks of max_batch frames only where a staging buffer of the context is involved
+    const int step = (in_on_device && out_on_device) ? B : c->maxB;
+    for (int b0 = 0; b0 < B; b0 += step) {
+        const int nb = std::min(step, B - b0);
+        const uint8_t* src = yuyv + (size_t)b0 * px * 2;
+        uint8_t* dst = bgr + (size_t)b0 * px * 3;
+        if (!in_on_device) {
+            HIPCHK(c, hipMemcpyAsync(c->d_in, src, (size_t)nb * px * 2, hipMemcpyHostToDevice, c->stream));
+            src = c->d_in;
+        }
+        launch_yuyv_bgr(src, out_on_device ? dst : c->d_uout, (size_t)nb * px, c->stream);
+        HIPCHK(c, hipGetLastError());
+        if (!out_on_device) HIPCHK(c, hipMemcpyAsync(dst, c->d_uout, (size_t)nb * px * 3, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return CAMSYNC_OK;
+}
+
 /* ---- calibration ---- */
 
 int camsync_calib_begin(camsync_ctx* c, const float* obj, const float* img, int V, int P, int flags) {

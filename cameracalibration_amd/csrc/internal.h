@@ -245,6 +245,7 @@ struct DetBuffers {
 void launch_gray_thresh(const DetCfg& c, const DetBuffers& b, int B, int C, hipStream_t st);
 // true when launch_gray_thresh runs the fused kernel, which can do without writing the gray image
 bool gray_thresh_is_fused(const DetCfg& c);
+void launch_yuyv_bgr(const uint8_t* d_yuyv, uint8_t* d_bgr, size_t px, hipStream_t st);
 void launch_contour_starts(const DetCfg& c, const DetBuffers& b, int B, hipStream_t st);
 void launch_trace(const DetCfg& c, const DetBuffers& b, hipStream_t st);
 void launch_quad_fit(const DetCfg& c, const DetBuffers& b, int B, hipStream_t st);

@@ -84,6 +84,16 @@ const char* camsync_last_error(const camsync_ctx* ctx);
 int camsync_host_alloc(void** out, size_t bytes);
 int camsync_host_free(void* p);
 
+/* What VideoCapture.read() does before the reference sees a frame (camera.py:150-154, capture opened at :98-118): a
+ * UVC camera delivers packed YUYV 4:2:2 (V4L2_PIX_FMT_YUYV, bytes Y0 U Y1 V per pixel pair) and OpenCV converts it to
+ * BGR on the CPU (cvtColor COLOR_YUV2BGR_YUYV: BT.601 limited range, 20-bit fixed point).  Here the raw frames are
+ * converted on the GPU: yuyv u8 [B,H,W,2] on the host or (in_on_device) on the GPU, 16-byte aligned there; bgr u8
+ * [B,H,W,3] on the GPU (out_on_device, 8-byte aligned: ready for camsync_detect_pnp_resident and the on_device form
+ * of every *_batch entry point) or on the host.  W must be a multiple of 8.  A raw frame is two thirds of a BGR one,
+ * so the host-to-device copy shrinks by a third as well. */
+int camsync_ingest_yuyv(camsync_ctx* ctx, const uint8_t* yuyv, int in_on_device, int B, int H, int W,
+                        uint8_t* bgr, int out_on_device);
+
 /* cv.aruco.DetectorParameters() (aruco.py:249-254). */
 void camsync_default_params(camsync_params* p);
 int camsync_set_params(camsync_ctx* ctx, const camsync_params* p);

@@ -156,6 +156,10 @@ int orc_undistort(const uint8_t* src, int H, int W, int C, const double* K, cons
  * cv.findChessboardCorners, see that file). */
 int orc_chess_candidates(const uint8_t* gray, int H, int W, int scale, int max_cand, int32_t* xy, int32_t* strength);
 
+/* Frame ingest (reference camera_sync/camera.py:104-118, 150-154: VideoCapture.read()): packed YUYV 4:2:2 as a UVC
+ * camera delivers it -> BGR, as cv.cvtColor(COLOR_YUV2BGR_YUYV) (oracle/ingest.cpp).  PARITY UNPINNED. */
+int orc_yuyv_to_bgr(const uint8_t* yuyv, int H, int W, uint8_t* bgr);
+
 #ifdef __cplusplus
 }
 #endif

@@ -264,3 +264,14 @@ def chess_candidates(gray, scale=1, max_cand=4096):
     n = lib().orc_chess_candidates(_p(g), h, w, int(scale), max_cand, _p(xy), _p(st))
     assert n <= max_cand
     return xy[:n], st[:n]
+
+
+def yuyv_to_bgr(yuyv):
+    """Packed YUYV [H,W,2] uint8 -> BGR [H,W,3] (oracle/ingest.cpp)."""
+    src = np.ascontiguousarray(yuyv, dtype=np.uint8)
+    h, w = src.shape[:2]
+    out = np.empty((h, w, 3), np.uint8)
+    rc = lib().orc_yuyv_to_bgr(_p(src), h, w, _p(out))
+    if rc:
+        raise ValueError("orc_yuyv_to_bgr: bad arguments")
+    return out
