@@ -561,6 +561,15 @@ struct WaveQueue {
     __device__ __forceinline__ bool empty() const { return drained && lo == hi; }
 };
 
+// Items per batch for n items over nWaves wavefronts: the full batch when there is plenty of work; otherwise just enough
+// for every item to be in some wavefront's first (static) batch, so that a small launch spreads over the whole chip
+// and touches the shared counter not at all (one 1080p frame has ~1000 seeds: with batches of 128 eight wavefronts
+// did all the work while 4088 looked on, and the pass took 375 us of the frame's 930).
+__device__ __forceinline__ unsigned int spread_batch(unsigned int n, unsigned int nWaves, unsigned int full) {
+    const unsigned int even = (n + nWaves - 1u) / (nWaves ? nWaves : 1u);
+    return even < 1u ? 1u : even < full ? even : full;
+}
+
 struct WaveAlloc {
     unsigned int cur = 0, end = 0;
     // set when a refill did not fit: the entries between the counter's old value and the capacity belong to
@@ -671,7 +680,8 @@ __global__ __launch_bounds__(256) void k_trace_short(const uint32_t* __restrict_
     };
 
     WaveQueue queue;
-    queue.start(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), gridDim.x * (blockDim.x >> 6), n, kShortBatch);
+    const unsigned int qBatch = spread_batch(n, gridDim.x * (blockDim.x >> 6), kShortBatch);
+    queue.start(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), gridDim.x * (blockDim.x >> 6), n, qBatch);
     // The wave's batch of candidates is read into LDS in one coalesced sweep when the batch is drawn: a lane that takes
     // up a candidate then has it after an LDS read instead of a trip to memory that the whole wave waits for.
     unsigned int batchLo = queue.lo;
@@ -700,10 +710,10 @@ __global__ __launch_bounds__(256) void k_trace_short(const uint32_t* __restrict_
         if (iter % kPick == 0 || !anyActive) {
             const bool need = !active && !exhausted;
             if (queue.lo == queue.hi && !queue.drained && __any(need)) {
-                queue.refill(&ctr->qShort, n, kShortBatch, lane);
+                queue.refill(&ctr->qShort, n, qBatch, lane);
                 load_batch();
             }
-            const unsigned int i = queue.pop<1>(need, &ctr->qShort, n, kShortBatch, lane);
+            const unsigned int i = queue.pop<1>(need, &ctr->qShort, n, qBatch, lane);
             if (need) {
                 if (i != ~0u) {
                     c = batch[i - batchLo];
@@ -911,7 +921,8 @@ __device__ __forceinline__ void seg_walk_items(const uint32_t* __restrict__ plan
     TileWin win;
     win.invalidate();
     WaveQueue queue;
-    queue.start(wave, nWaves, nMine, kWalkBatch);
+    const unsigned int qBatch = spread_batch(nMine, nWaves, kWalkBatch);
+    queue.start(wave, nWaves, nMine, qBatch);
 
     // Everything that touches global memory or is rare -- writing a finished segment's record, taking up the next
     // work item, moving a lane's window -- happens in a service phase every kService steps, for all lanes that need
@@ -956,7 +967,7 @@ __device__ __forceinline__ void seg_walk_items(const uint32_t* __restrict__ plan
             // ---- lanes without a next item draw one (its load is in flight while the current item is followed) ----
             {
                 const bool need = nextI == ~0u && !exhausted;
-                const unsigned int i = queue.pop<1>(need, head, nMine, kWalkBatch, lane);
+                const unsigned int i = queue.pop<1>(need, head, nMine, qBatch, lane);
                 if (need) {
                     if (i != ~0u) {
                         nextI = base + i;
@@ -1120,13 +1131,14 @@ __global__ __launch_bounds__(64) void k_resolve(DetCfg cfg, const uint64_t* __re
     const unsigned int virtLo = segCap - min(ctr->nVirt, segCap - nItems);  // continuation ids are >= virtLo
     const unsigned int hopCap = (unsigned int)cfg.maxPerim + 4u * (unsigned int)kSegLen;  // no ring is longer (in segments) than this
     WaveQueue queue;
-    queue.start(blockIdx.x, gridDim.x, nCand, kResolveBatch);
+    const unsigned int qBatch = spread_batch(nCand, gridDim.x, kResolveBatch);
+    queue.start(blockIdx.x, gridDim.x, nCand, qBatch);
     bool exhausted = false;
 
     auto valid_id = [&](uint32_t v) { return v < nItems || (v >= virtLo && v < segCap); };
 
     for (;;) {
-        const unsigned int i = queue.pop<1>(!exhausted, &ctr->qResolve, nCand, kResolveBatch, lane);
+        const unsigned int i = queue.pop<1>(!exhausted, &ctr->qResolve, nCand, qBatch, lane);
         const bool have = !exhausted && i != ~0u;
         if (!exhausted && i == ~0u && queue.empty()) exhausted = true;
         if (__all(exhausted)) break;
