@@ -82,14 +82,25 @@ __device__ bool marker_in_marker(const float* m1, const float* m2) {
 
 // NQ: capacity of the LDS working set.  Two instances run over every frame: the small one takes the frames with
 // up to 256 candidates (nearly all of them, at a quarter of the LDS), the large one the rest.
-template <int NQ>
-__global__ __launch_bounds__(64) void k_select(const QuadRec* __restrict__ quads, const int* __restrict__ qcount,
+// NT: threads per frame.  The phases are loops over candidates, pairs or groups that any number of wavefronts can
+// share; what depends on the order of the sequential algorithm (group bookkeeping, acceptance) runs on thread 0, from
+// what the others have laid out in LDS.  One wavefront per frame gives the best throughput when there are thousands of
+// frames with a few dozen candidates each; with hundreds of candidates per frame (4K frames, forty markers at three
+// scales) or few frames, a frame's chain of LDS round trips is the whole stage's time and four wavefronts share it.
+constexpr int kGroupRound = 16;  // candidates whose pair tests are laid out before thread 0 replays them
+
+template <int NQ, int NT>
+__global__ __launch_bounds__(NT) void k_select(const QuadRec* __restrict__ quads, const int* __restrict__ qcount,
                                                DetCfg cfg, int32_t* __restrict__ outIds, float* __restrict__ outCorners, float* __restrict__ rawCorners,
                                                int32_t* __restrict__ outCounts, float* __restrict__ outRejected,
                                                int32_t* __restrict__ outRejCounts, MarkerRec* __restrict__ markers,
                                                unsigned int markerCap, Counters* __restrict__ ctr) {
+    constexpr int NW = NT / 64;       // wavefronts
+    constexpr int NB = NQ / 64;       // blocks of 64 candidates
+    constexpr int PER = (NQ + NT - 1) / NT;  // candidates per thread
     __shared__ float s_c[NQ][8];      // corners, sorted order
     __shared__ float s_perim[NQ];
+    __shared__ float s_cenx[NQ], s_ceny[NQ], s_thr[NQ];  // centroid, and perimeter x minMarkerDistanceRate, of the sorted candidates
     __shared__ int s_rank[NQ];
     __shared__ short s_gid[NQ];
     __shared__ short s_closeOf[NQ];   // representative this candidate is a fall-back of, or -1
@@ -100,53 +111,60 @@ __global__ __launch_bounds__(64) void k_select(const QuadRec* __restrict__ quads
     __shared__ uint8_t s_acc[NQ], s_was[NQ], s_seen[NQ];
     __shared__ short s_use[NQ];       // candidate whose corners/id are reported for a selected entry
     __shared__ int s_nGroups, s_nSel;
+    __shared__ unsigned long long s_close[kGroupRound][NB];  // per candidate of the round and block: the later candidates close to it
+    __shared__ uint32_t s_closeBlocks[kGroupRound];            // ... and which blocks have any
 
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int f = blockIdx.x;
     const int n = min(qcount[f], kQuadCap);
     if ((n > 256) != (NQ > 256)) return;  // the other instance's frame
     const QuadRec* __restrict__ Q = quads + (size_t)f * kQuadCap;
 
     if (n == 0) {
-        if (lane == 0) { outCounts[f] = 0; outRejCounts[f] = 0; }
+        if (tid == 0) { outCounts[f] = 0; outRejCounts[f] = 0; }
         return;
     }
 
     // ---- order: rank by (perimeter desc, scale asc, scanKey desc) ----
-    // perimeter needs the corners first; stage unsorted corners in s_c rows
-    for (int i = lane; i < n; i += 64) {
+    // perimeter needs the corners first
+    for (int i = tid; i < n; i += NT) {
         float c[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) c[k] = (float)Q[i].c[k];
         s_perim[i] = perimeter4(c);
+        // (scale asc, scan key desc) as one ascending key: scan keys are pixel positions (< 2^24), scales < 8
+        s_rank[i] = (int)((Q[i].scale << 24) | (0xFFFFFFu - (Q[i].scanKey & 0xFFFFFFu)));
     }
-    // (scale asc, scan key desc) as one ascending key, staged in LDS: scan keys are pixel positions (< 2^24), scales < 8
-    for (int i = lane; i < n; i += 64) s_rank[i] = (int)((Q[i].scale << 24) | (0xFFFFFFu - (Q[i].scanKey & 0xFFFFFFu)));
     __syncthreads();
-    int myRank[NQ / 64];
+    // one pass over the candidates for all of a thread's own (up to PER) candidates: the two LDS reads of a step
+    // are shared by them, and successive steps do not depend on one another
+    int myRank[PER];
+    float myPerim[PER];
+    uint32_t myKey[PER];
 #pragma unroll
-    for (int t = 0; t < NQ / 64; t++) {
-        const int i = lane + 64 * t;
-        int r = 0;
-        if (i < n) {
-            const float pi = s_perim[i];
-            const uint32_t ki = (uint32_t)s_rank[i];
-            for (int j = 0; j < n; j++) {
-                const float pj = s_perim[j];
-                const uint32_t kj = (uint32_t)s_rank[j];
-                // j comes before i (never true for j == i)
-                const bool before = (pj != pi) ? pj > pi : kj < ki;
-                r += before ? 1 : 0;
-            }
+    for (int t = 0; t < PER; t++) {
+        const int i = min(tid + NT * t, n - 1);
+        myRank[t] = 0;
+        myPerim[t] = s_perim[i];
+        myKey[t] = (uint32_t)s_rank[i];
+    }
+    for (int j = 0; j < n; j++) {
+        const float pj = s_perim[j];
+        const uint32_t kj = (uint32_t)s_rank[j];
+#pragma unroll
+        for (int t = 0; t < PER; t++) {
+            if (NT * t >= n) break;  // (uniform)
+            // j comes before i (never true for j == i)
+            const bool before = (pj != myPerim[t]) ? pj > myPerim[t] : kj < myKey[t];
+            myRank[t] += before ? 1 : 0;
         }
-        myRank[t] = r;
     }
     __syncthreads();
 #pragma unroll
-    for (int t = 0; t < NQ / 64; t++)
-        if (lane + 64 * t < n) s_rank[lane + 64 * t] = myRank[t];
+    for (int t = 0; t < PER; t++)
+        if (tid + NT * t < n) s_rank[tid + NT * t] = myRank[t];
     __syncthreads();
-    for (int i = lane; i < n; i += 64) {
+    for (int i = tid; i < n; i += NT) {
         const int r = s_rank[i];
 #pragma unroll
         for (int k = 0; k < 8; k++) s_c[r][k] = (float)Q[i].c[k];
@@ -155,65 +173,123 @@ __global__ __launch_bounds__(64) void k_select(const QuadRec* __restrict__ quads
         s_valid[r] = (uint8_t)Q[i].valid;
     }
     __syncthreads();
-    for (int i = lane; i < n; i += 64) {
+    const float rate = cfg.minMarkerDistanceRate;
+    for (int i = tid; i < n; i += NT) {
         s_perim[i] = perimeter4(s_c[i]);
+        s_cenx[i] = 0.25f * (s_c[i][0] + s_c[i][2] + s_c[i][4] + s_c[i][6]);
+        s_ceny[i] = 0.25f * (s_c[i][1] + s_c[i][3] + s_c[i][5] + s_c[i][7]);
+        s_thr[i] = s_perim[i] * rate;
         s_gid[i] = -1;
         s_closeOf[i] = -1;
         s_isSel[i] = 1;
     }
-    if (lane == 0) s_nGroups = 0;
     __syncthreads();
 
     // ---- group near-duplicates ----
-    const float rate = cfg.minMarkerDistanceRate;
-    for (int i = 0; i < n; i++) {
-        const float cix = 0.25f * (s_c[i][0] + s_c[i][2] + s_c[i][4] + s_c[i][6]), ciy = 0.25f * (s_c[i][1] + s_c[i][3] + s_c[i][5] + s_c[i][7]);
-        for (int j0 = i + 1; j0 < n; j0 += 64) {
-            const int j = j0 + lane;
-            bool close = false;
-            if (j < n) {
-                // the mean distance of matched corners is at least the distance of the centroids: pairs whose centroids
-                // are clearly further apart than the bound (1 % and a pixel of slack for rounding) cannot be close
-                const float thr = s_perim[j] * rate;
-                const float dx = 0.25f * (s_c[j][0] + s_c[j][2] + s_c[j][4] + s_c[j][6]) - cix;
-                const float dy = 0.25f * (s_c[j][1] + s_c[j][3] + s_c[j][5] + s_c[j][7]) - ciy;
-                const float lim = thr * 1.01f + 1.f;
-                if (dx * dx + dy * dy <= lim * lim) close = avg_distance(s_c[i], s_c[j]) < thr;
-            }
-            unsigned long long m = __ballot(close);
-            if (lane == 0) {
-                while (m) {
-                    const int jj = j0 + __ffsll((long long)m) - 1;
-                    m &= m - 1;
-                    s_isSel[i] = 0;
-                    s_isSel[jj] = 0;
-                    const int gi = s_gid[i], gj = s_gid[jj];
-                    if (gi < 0 && gj < 0) {
-                        s_gid[i] = s_gid[jj] = (short)s_nGroups;
-                        s_nGroups = s_nGroups + 1;
-                    } else if (gi > -1 && gj == -1) {
-                        s_gid[jj] = (short)gi;
-                    } else if (gj > -1 && gi == -1) {
-                        s_gid[i] = (short)gj;
-                    }
+    // Rounds of kGroupRound candidates.  The wavefronts share the round's candidates; for candidate i a wavefront
+    // tests the later candidates 64 at a time: first the centroids (the mean distance of matched corners is at least
+    // the distance of the centroids, so pairs whose centroids are clearly further apart than the bound -- 1 % and a
+    // pixel of slack for rounding -- cannot be close), then the corner distances of the pairs that are left, and
+    // leaves a mask of the close ones per block.  Thread 0 then replays the round's pairs in the order of the
+    // sequential algorithm (i ascending, j ascending) and keeps the groups' books, with candidate i's group id and
+    // the group count in registers.
+    int nG = 0;  // (thread 0's count of groups)
+    const int nBlocks = (n + 63) >> 6;
+    for (int i0 = 0; i0 < n; i0 += kGroupRound) {
+        for (int slot = wave; slot < kGroupRound; slot += NW) {
+            const int i = i0 + slot;
+            if (i >= n) break;  // (uniform per wavefront)
+            const float cix = s_cenx[i], ciy = s_ceny[i];
+            uint32_t blocks = 0;
+            for (int b = (i + 1) >> 6; b < nBlocks; b++) {
+                const int j = 64 * b + lane;
+                bool nr = false;
+                if (j > i && j < n) {
+                    const float dx = s_cenx[j] - cix, dy = s_ceny[j] - ciy;
+                    const float lim = s_thr[j] * 1.01f + 1.f;
+                    nr = dx * dx + dy * dy <= lim * lim;
+                }
+                if (!__any(nr)) continue;
+                bool close = false;
+                if (nr) close = avg_distance(s_c[i], s_c[j]) < s_thr[j];
+                const unsigned long long m = __ballot(close);
+                if (m) {
+                    blocks |= 1u << b;
+                    if (lane == 0) s_close[slot][b] = m;
                 }
             }
-            __syncthreads();
+            if (lane == 0) s_closeBlocks[slot] = blocks;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            for (int slot = 0; slot < kGroupRound && i0 + slot < n; slot++) {
+                uint32_t blocks = s_closeBlocks[slot];
+                if (!blocks) continue;
+                const int i = i0 + slot;
+                int gi = s_gid[i];
+                while (blocks) {
+                    const int b = __ffs((int)blocks) - 1;
+                    blocks &= blocks - 1;
+                    unsigned long long m = s_close[slot][b];
+                    while (m) {
+                        const int jj = 64 * b + __ffsll((long long)m) - 1;
+                        m &= m - 1;
+                        s_isSel[jj] = 0;
+                        const int gj = s_gid[jj];
+                        if (gi < 0 && gj < 0) {
+                            gi = nG++;
+                            s_gid[jj] = (short)gi;
+                        } else if (gi > -1 && gj == -1) {
+                            s_gid[jj] = (short)gi;
+                        } else if (gj > -1 && gi == -1) {
+                            gi = gj;
+                        }
+                    }
+                }
+                s_gid[i] = (short)gi;
+                s_isSel[i] = 0;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) s_nGroups = nG;
+    __syncthreads();
+
+    // ---- representative + fall-backs per group (one group per thread) ----
+    // The members of every group are listed first (ascending, as the sequential algorithm meets them), so that the
+    // threads then walk their groups in step: with each thread scanning all candidates for its own, the expensive part
+    // ran once per candidate of the frame instead of once per position in the largest group.  Scratch: s_rank (member
+    // counts, free between the sort and the fall-back ranks), s_parent (offsets) and s_use (members), which the
+    // containment phase initialises later.
+    const int nGroups = s_nGroups;
+    for (int g = tid; g < nGroups; g += NT) s_rank[g] = 0;
+    __syncthreads();
+    for (int id = tid; id < n; id += NT) {
+        const int g = s_gid[id];
+        if (g >= 0) atomicAdd(&s_rank[g], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int off = 0;
+        for (int g = 0; g < nGroups; g++) {
+            s_parent[g] = (short)off;
+            off += s_rank[g];
         }
     }
     __syncthreads();
-
-    // ---- representative + fall-backs per group (one group per lane) ----
-    const int nGroups = s_nGroups;
-    for (int g = lane; g < nGroups; g += 64) {
-        int first = -1, curr = -1;
-        for (int id = 0; id < n; id++) {
-            if (s_gid[id] != g) continue;
-            if (first < 0) {
-                first = curr = id;
-                s_isSel[id] = 1;
-                continue;
-            }
+    for (int g = tid; g < nGroups; g += NT) {
+        int k = s_parent[g];
+        for (int id = 0; id < n; id++)
+            if (s_gid[id] == g) s_use[k++] = (short)id;
+    }
+    __syncthreads();
+    for (int g = tid; g < nGroups; g += NT) {
+        const int off = s_parent[g], cnt = s_rank[g];
+        const int first = s_use[off];
+        int curr = first;
+        s_isSel[first] = 1;
+        for (int m = 1; m < cnt; m++) {
+            const int id = s_use[off + m];
             const float dist = avg_distance(s_c[id], s_c[curr]);
             float ms = 0.f;
 #pragma unroll
@@ -228,18 +304,23 @@ __global__ __launch_bounds__(64) void k_select(const QuadRec* __restrict__ quads
     }
     __syncthreads();
 
-    // ---- selected list (ascending) ----
-    if (lane == 0) {
-        int ns = 0;
-        for (int i = 0; i < n; i++)
-            if (s_isSel[i]) s_sel[ns++] = (short)i;
-        s_nSel = ns;
+    // ---- selected list (ascending): positions by ballot, 64 candidates at a time, on the first wavefront ----
+    if (wave == 0) {
+        int ns0 = 0;  // uniform
+        for (int i0 = 0; i0 < n; i0 += 64) {
+            const int i = i0 + lane;
+            const bool sel = i < n && s_isSel[i];
+            const unsigned long long bal = __ballot(sel);
+            if (sel) s_sel[ns0 + (int)__popcll(bal & ((1ull << lane) - 1ull))] = (short)i;
+            ns0 += (int)__popcll(bal);
+        }
+        if (lane == 0) s_nSel = ns0;
     }
     __syncthreads();
     const int ns = s_nSel;
 
     // ---- containment hierarchy ----
-    for (int k = lane; k < ns; k += 64) {
+    for (int k = tid; k < ns; k += NT) {
         int parent = -1;
         for (int j = k - 1; j >= 0; j--)
             if (marker_in_marker(s_c[s_sel[k]], s_c[s_sel[j]])) { parent = j; break; }
@@ -250,19 +331,17 @@ __global__ __launch_bounds__(64) void k_select(const QuadRec* __restrict__ quads
         s_seen[k] = 0;
         s_use[k] = s_sel[k];
     }
+    // first valid fall-back of every representative (smallest index), found by all threads: the acceptance loop below
+    // runs on one thread and used to scan the candidates after each invalid one (s_rank is free again: reused)
+    for (int i = tid; i < n; i += NT) s_rank[i] = 0x7FFFFFFF;
     __syncthreads();
-
-    // first valid fall-back of every representative (smallest index), found by all lanes: the acceptance loop below runs
-    // on one lane and used to scan the candidates after each invalid one (s_rank is free again: reused)
-    for (int i = lane; i < n; i += 64) s_rank[i] = 0x7FFFFFFF;
-    __syncthreads();
-    for (int id = lane; id < n; id += 64) {
+    for (int id = tid; id < n; id += NT) {
         const int c = s_closeOf[id];
         if (c >= 0 && s_valid[id]) atomicMin(&s_rank[c], id);
     }
     __syncthreads();
 
-    if (lane == 0) {
+    if (tid == 0) {
         int maxDepth = 0;
         for (int i = ns - 1; i >= 0; i--) {
             const int p = s_parent[i];
@@ -298,44 +377,63 @@ __global__ __launch_bounds__(64) void k_select(const QuadRec* __restrict__ quads
             }
             depth++;
         }
+    }
+    __syncthreads();
+    if (wave != 0) return;
 
-        // ---- outputs ----
-        int na = 0, nr = 0;
-        for (int v = 0; v < ns; v++) {
-            if (s_seen[v] && s_acc[v]) {
-                if (na < kMaxMarkerOut) {
-                    const int u = s_use[v];
-                    const int rot = s_rot[u];
-                    // correctCornerPosition: std::rotate(begin, begin + 4 - rot, end)
-                    float* o = outCorners + ((size_t)f * kMaxMarkerOut + na) * 8;
-                    float* o2 = rawCorners + ((size_t)f * kMaxMarkerOut + na) * 8;
-                    for (int k = 0; k < 4; k++) {
-                        const int src = (k + 4 - rot) & 3;
-                        o[2 * k] = o2[2 * k] = s_c[u][2 * src];
-                        o[2 * k + 1] = o2[2 * k + 1] = s_c[u][2 * src + 1];
-                    }
-                    outIds[(size_t)f * kMaxMarkerOut + na] = s_id[u];
-                    const unsigned int slot = atomicAdd(&ctr->nMarkers, 1u);
-                    if (slot < markerCap) {
-                        markers[slot].frame = (uint32_t)f;
-                        markers[slot].slot = (uint32_t)na;
-                    } else {
-                        atomicOr(&ctr->overflow, 32u);
-                    }
-                    na++;
+    // ---- outputs: accepted markers and rejected candidates in the order of the selected list, 64 entries at a time
+    //      (positions by ballot; every lane of the first wavefront writes its own entry) ----
+    int na = 0, nr = 0;  // uniform
+    for (int v0 = 0; v0 < ns; v0 += 64) {
+        const int v = v0 + lane;
+        const bool in = v < ns;
+        const bool isAcc = in && s_seen[v] && s_acc[v];
+        const unsigned long long balA = __ballot(isAcc), balR = __ballot(in && !isAcc);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        const int myA = na + (int)__popcll(balA & below), myR = nr + (int)__popcll(balR & below);
+        const int cntA = (int)__popcll(balA);
+        // marker records: one reservation for the chunk's markers that fit the frame's output
+        const int fit = max(0, min(cntA, kMaxMarkerOut - na));
+        unsigned int slot0 = 0;
+        if (fit > 0) {
+            if (lane == 0) slot0 = atomicAdd(&ctr->nMarkers, (unsigned int)fit);
+            slot0 = (unsigned int)__builtin_amdgcn_readfirstlane((int)slot0);
+        }
+        if (isAcc) {
+            if (myA < kMaxMarkerOut) {
+                const int u = s_use[v];
+                const int rot = s_rot[u];
+                // correctCornerPosition: std::rotate(begin, begin + 4 - rot, end)
+                float* o = outCorners + ((size_t)f * kMaxMarkerOut + myA) * 8;
+                float* o2 = rawCorners + ((size_t)f * kMaxMarkerOut + myA) * 8;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int src = (k + 4 - rot) & 3;
+                    o[2 * k] = o2[2 * k] = s_c[u][2 * src];
+                    o[2 * k + 1] = o2[2 * k + 1] = s_c[u][2 * src + 1];
+                }
+                outIds[(size_t)f * kMaxMarkerOut + myA] = s_id[u];
+                const unsigned int slot = slot0 + (unsigned int)(myA - na);
+                if (slot < markerCap) {
+                    markers[slot].frame = (uint32_t)f;
+                    markers[slot].slot = (uint32_t)myA;
                 } else {
                     atomicOr(&ctr->overflow, 32u);
                 }
             } else {
-                if (nr < kMaxRejectedOut) {
-                    float* o = outRejected + ((size_t)f * kMaxRejectedOut + nr) * 8;
-                    const int u = s_sel[v];
-                    for (int k = 0; k < 8; k++) o[k] = s_c[u][k];
-                }
-                nr++;
+                atomicOr(&ctr->overflow, 32u);
             }
+        } else if (in && myR < kMaxRejectedOut) {
+            float* o = outRejected + ((size_t)f * kMaxRejectedOut + myR) * 8;
+            const int u = s_sel[v];
+#pragma unroll
+            for (int k = 0; k < 8; k++) o[k] = s_c[u][k];
         }
-        outCounts[f] = na;
+        na += cntA;
+        nr += (int)__popcll(balR);
+    }
+    if (lane == 0) {
+        outCounts[f] = min(na, kMaxMarkerOut);
         outRejCounts[f] = min(nr, kMaxRejectedOut);
     }
 }
@@ -372,10 +470,16 @@ void launch_export_markers(const DetBuffers& b, int B, int maxMarkers, int32_t* 
 }
 
 void launch_select(const DetCfg& c, const DetBuffers& b, int B, hipStream_t st) {
-    hipLaunchKernelGGL(k_select<256>, dim3(B), dim3(64), 0, st, b.quads, b.qcount, c, b.outIds, b.outCorners, b.rawCorners, b.outCounts,
-                       b.outRejected, b.outRejCounts, b.markers, b.markerCap, b.counters);
-    hipLaunchKernelGGL(k_select<kQuadCap>, dim3(B), dim3(64), 0, st, b.quads, b.qcount, c, b.outIds, b.outCorners, b.rawCorners, b.outCounts,
-                       b.outRejected, b.outRejCounts, b.markers, b.markerCap, b.counters);
+    // frames with up to 256 candidates: one wavefront per frame when there are frames enough to fill the chip that way,
+    // four otherwise (latency of a small batch); frames with more candidates always get four
+    if (B >= 1024)
+        hipLaunchKernelGGL((k_select<256, 64>), dim3(B), dim3(64), 0, st, b.quads, b.qcount, c, b.outIds, b.outCorners, b.rawCorners,
+                           b.outCounts, b.outRejected, b.outRejCounts, b.markers, b.markerCap, b.counters);
+    else
+        hipLaunchKernelGGL((k_select<256, 256>), dim3(B), dim3(256), 0, st, b.quads, b.qcount, c, b.outIds, b.outCorners, b.rawCorners,
+                           b.outCounts, b.outRejected, b.outRejCounts, b.markers, b.markerCap, b.counters);
+    hipLaunchKernelGGL((k_select<kQuadCap, 256>), dim3(B), dim3(256), 0, st, b.quads, b.qcount, c, b.outIds, b.outCorners, b.rawCorners,
+                       b.outCounts, b.outRejected, b.outRejCounts, b.markers, b.markerCap, b.counters);
 }
 
 }  // namespace camsync
