@@ -1470,7 +1470,9 @@ void launch_contour_starts(const DetCfg& c, const DetBuffers& b, int B, hipStrea
     const long long waves = (long long)B * c.nScales * colGroups;
     const int totalGroups = plane_hb(c.H) * 4;
     int bands = 1;
-    if (waves < 256 * 16) bands = (int)std::min<long long>((256 * 16 + waves - 1) / waves, (totalGroups + 3) / 4);
+    // (about 32 wavefronts per CU: the chip holds ~26 of them per CU, and one round that does not fill it runs at the
+    // latency of its loads -- 256 4K frames: 0.66 ms with 16 per CU, 0.58 ms with 32)
+    if (waves < 256 * 32) bands = (int)std::min<long long>((256 * 32 + waves - 1) / waves, (totalGroups + 3) / 4);
     // a wavefront that takes a whole plane runs long, and the chip holds ~26 of them per CU: with one or two rounds of
     // such wavefronts the last ones run on a half-empty chip (12288 planes: 2.08 ms in one band, 1.70 ms in three; more
     // bands than needed cost an atomic per list and wavefront on two shared counters: 2.6 ms with eighteen)
