@@ -103,6 +103,7 @@ def load_library() -> C.CDLL:
         lib.camsync_debug_points.argtypes = [vp, i32, i32, vp]
         lib.camsync_debug_limit_capacity.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32]
         lib.camsync_debug_restore_capacity.argtypes = [vp]
+        lib.camsync_debug_identify_all.argtypes = [vp, i32]
         lib.camsync_pnp_batch.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, vp, vp, vp]
         lib.camsync_pnp_batch_noalloc.argtypes = lib.camsync_pnp_batch.argtypes
         lib.camsync_ippe_square_batch.argtypes = [vp, vp, vp, i32, vp, vp, i32, i32, vp, vp, vp]
@@ -299,6 +300,10 @@ class Context:
             self._check(n)
         assert n <= cap
         return np.sort(out[:n])
+
+    def debug_identify_all(self, on=True):
+        """Identify every quad candidate in the following calls (debug_quads then reports an id for each)."""
+        self._check(self._lib.camsync_debug_identify_all(self._h, 1 if on else 0))
 
     def debug_quads(self, frame=0, cap=1024):
         c = np.zeros((cap, 4, 2), np.float32)

@@ -489,6 +489,10 @@ int camsync_create(camsync_ctx** out, int device, int max_h, int max_w, int max_
     HIPCHK(c, dalloc(&b.resolveLog, (size_t)b.resolveWaves * kResolveLogHops * 64));
     HIPCHK(c, dalloc(&b.quads, B * kQuadCap));
     HIPCHK(c, dalloc(&b.persp, B * kQuadCap * 10));
+    HIPCHK(c, dalloc(&b.idList, B * kQuadCap));
+    HIPCHK(c, dalloc(&b.idCount, B * 2));
+    HIPCHK(c, dalloc(&b.selState, B * 3 * kQuadCap));
+    b.identifyAll = 0;
     HIPCHK(c, dalloc(&b.qcount, B));
     HIPCHK(c, dalloc(&b.counters, 1));
     b.markerCap = (unsigned)(B * kMaxMarkerOut);
@@ -536,7 +540,7 @@ void camsync_destroy(camsync_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DetBuffers& b = c->buf;
     void* ptrs[] = {c->d_chessGray, c->d_chessS, c->d_chessR, c->d_chessCand, c->d_chessMax, c->d_chessCount, c->d_spIn, c->d_spOut, c->d_spN,
-                    c->d_umap, c->d_uout, c->d_in, c->d_bin, b.planes, b.gray, b.cand, b.candLong, b.contours, b.pool, b.tasks, b.seeds, b.seg, b.seedTable, b.chain, b.copies, b.resolveLog, b.quads, b.persp, b.qcount, b.counters, b.markers,
+                    c->d_umap, c->d_uout, c->d_in, c->d_bin, b.planes, b.gray, b.cand, b.candLong, b.contours, b.pool, b.tasks, b.seeds, b.seg, b.seedTable, b.chain, b.copies, b.resolveLog, b.quads, b.persp, b.idList, b.idCount, b.selState, b.qcount, b.counters, b.markers,
                     b.outIds, b.outCorners, b.rawCorners, b.outCounts, b.outRejected, b.outRejCounts, c->d_dict, c->d_expTab,
                     c->d_obj, c->d_img, c->d_npts, c->d_K, c->d_dist, c->d_rvec, c->d_tvec, c->d_mae, c->d_rmse, c->d_ok,
                     c->d_anchorIds, c->d_anchorObj, c->d_calObj, c->d_calImg, c->cal.intr, c->cal.ext, c->cal.intrTrial,
@@ -829,6 +833,12 @@ int camsync_debug_limit_capacity(camsync_ctx* c, unsigned int contours, unsigned
         b.taskCap = std::min(tasks, c->allocTaskCap);
         b.copyCap = b.taskCap;
     }
+    return CAMSYNC_OK;
+}
+
+int camsync_debug_identify_all(camsync_ctx* c, int on) {
+    if (!c) return CAMSYNC_E_ARG;
+    c->buf.identifyAll = on ? 1 : 0;
     return CAMSYNC_OK;
 }
 

@@ -238,6 +238,11 @@ struct DetBuffers {
     uint4* resolveLog;      // [resolveWaves, kResolveLogHops, 64] records visited by k_resolve's first pass (chunk, start, len)
     unsigned int resolveWaves;  // waves of k_resolve (each owns a slice of the log)
     double* persp;          // [B, kQuadCap, 10] inverse perspective map of every quad + usable flag (k_quad_persp)
+    uint32_t* idList;       // [B, kQuadCap] quads to identify (k_group): from the front the candidates selected by the grouping
+                            // (quad index | 0xFFFF << 16), from the back their fall-backs (quad index | representative << 16)
+    int* idCount;           // [B, 2] entries at the front / at the back
+    int16_t* selState;      // [B, 3, kQuadCap] k_group's order, selection flags and fall-back relation for the final k_select
+    int identifyAll;        // debug: identify every quad candidate, not only the ones the selection can ask for
     const float* expTab;    // [21][41] separable cornerSubPix weights
 };
 
@@ -251,6 +256,7 @@ void launch_trace(const DetCfg& c, const DetBuffers& b, hipStream_t st);
 void launch_quad_fit(const DetCfg& c, const DetBuffers& b, int B, hipStream_t st);
 void launch_identify(const DetCfg& c, const DetBuffers& b, int B, hipStream_t st);
 void launch_select(const DetCfg& c, const DetBuffers& b, int B, hipStream_t st);
+void launch_group(const DetCfg& c, const DetBuffers& b, int B, hipStream_t st);
 void launch_subpix(const DetCfg& c, const DetBuffers& b, int B, hipStream_t st);
 void launch_export_markers(const DetBuffers& b, int B, int maxMarkers, int32_t* dIds, float* dCorners, int32_t* dCounts,
                            hipStream_t st);

@@ -121,25 +121,29 @@ __global__ __launch_bounds__(64) void k_quad_persp(const QuadRec* __restrict__ q
 }
 
 // Quads are taken 32 at a time by a workgroup of four waves.  Sampling, histogram, cell votes and dictionary search
-// are 64 lanes per quad (eight quads per wave, one after the other).  getThreshVal_Otsu's loop carries (q1, mu1) from
+// are 64 lanes per quad (the batch's quads interleaved over the waves, one after the other in each).  getThreshVal_Otsu's loop carries (q1, mu1) from
 // bin to bin through a division, so it is sequential: a few thousand dependent instructions per quad, which one wave
 // runs for the 32 quads side by side, one lane each, while the other three wait.
-constexpr int kIdBatch = 32, kIdWaves = 4, kIdPerWave = kIdBatch / kIdWaves;
+constexpr int kIdBatch = 32, kIdWaves = 4;
 
 // ROUNDS x 64 >= samples of a patch (9: the reference's 24 x 24 patch; 16: the largest patch check_params lets through)
 template <int kIdRounds>
 __global__ __launch_bounds__(64 * kIdWaves) void k_identify(const uint8_t* __restrict__ gray, int grayC, QuadRec* __restrict__ quads,
                                                             const int* __restrict__ qcount, const uint16_t* __restrict__ dictRot,
-                                                            const double* __restrict__ persp, DetCfg cfg) {
+                                                            const double* __restrict__ persp, DetCfg cfg,
+                                                            const uint32_t* __restrict__ idList, const int* __restrict__ idCount, int pass) {
     extern __shared__ __align__(16) uint8_t s_imgs[];  // kIdBatch patches of imgStride bytes
     __shared__ int s_histw[kIdWaves][256];             // the histograms being built (atomics), one per wave
     __shared__ uint16_t s_hist[kIdBatch][256];         // the batch's histograms (counts <= 1024)
     __shared__ double s_mu[kIdBatch];
-    __shared__ int s_first[kIdBatch], s_last[kIdBatch], s_mode[kIdBatch], s_thr[kIdBatch];
+    __shared__ int s_first[kIdBatch], s_last[kIdBatch], s_mode[kIdBatch], s_thr[kIdBatch], s_quad[kIdBatch];
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int f = blockIdx.x;  // (fast index: see k_quad_persp)
-    const int nq = min(qcount[f], kQuadCap);
+    // pass 0: every quad of the frame; 1: the candidates the grouping selected; 2: the fall-backs of the selected ones
+    // that pass 1 found invalid (k_group lists both kinds)
+    const int nq = pass == 0 ? min(qcount[f], kQuadCap) : min(idCount[2 * f + pass - 1], kQuadCap);
+    const uint32_t* const list = idList + (size_t)f * kQuadCap;
     const int H = cfg.H, W = cfg.W;
     const int nb = cfg.markerSize + 2 * cfg.borderBits;
     const int cell = cfg.cellSize;
@@ -159,8 +163,16 @@ __global__ __launch_bounds__(64 * kIdWaves) void k_identify(const uint8_t* __res
         const int nbq = min(kIdBatch, nq - base);
         __syncthreads();  // (the previous round's phase 3 has read what phase 1 overwrites)
         // ---- phase 1, quad by quad in every wave: samples, histogram, mean / standard deviation ----
-        for (int b = wave * kIdPerWave; b < min(nbq, (wave + 1) * kIdPerWave); b++) {
-            const double* mp = persp + ((size_t)f * kQuadCap + base + b) * 10;
+        for (int b = wave; b < nbq; b += kIdWaves) {  // (interleaved: a short list still occupies all the waves)
+            const uint32_t entry = pass == 0 ? (uint32_t)(base + b) : pass == 1 ? list[base + b] : list[kQuadCap - 1 - (base + b)];
+            const int q = (int)(entry & 0xFFFFu);
+            if (lane == 0) s_quad[b] = q;
+            if (pass == 2 && quads[(size_t)f * kQuadCap + (entry >> 16)].valid) {
+                // the representative was identified: its fall-backs are never asked for
+                if (lane == 0) s_mode[b] = 3;
+                continue;
+            }
+            const double* mp = persp + ((size_t)f * kQuadCap + q) * 10;
             double mi[9];
 #pragma unroll
             for (int i = 0; i < 9; i++) mi[i] = mp[i];
@@ -284,9 +296,10 @@ __global__ __launch_bounds__(64 * kIdWaves) void k_identify(const uint8_t* __res
         }
         __syncthreads();
         // ---- phase 3, quad by quad in every wave: cell votes, border test, dictionary ----
-        for (int b = wave * kIdPerWave; b < min(nbq, (wave + 1) * kIdPerWave); b++) {
-            QuadRec* qr = &quads[(size_t)f * kQuadCap + base + b];
+        for (int b = wave; b < nbq; b += kIdWaves) {  // (interleaved: a short list still occupies all the waves)
             const int mode = s_mode[b];
+            if (mode == 3) continue;
+            QuadRec* qr = &quads[(size_t)f * kQuadCap + s_quad[b]];
             uint64_t bitsMask;  // bit (y*nb+x) of the nb x nb grid
             if (mode) {
                 bitsMask = (mode == 1) ? ~0ull : 0ull;
@@ -366,11 +379,25 @@ void launch_identify(const DetCfg& c, const DetBuffers& b, int B, hipStream_t st
     const int S = (c.markerSize + 2 * c.borderBits) * c.cellSize;
     const size_t lds = (size_t)kIdBatch * ((S * S + 15) & ~15);
     hipLaunchKernelGGL(k_quad_persp, dim3(B, 2), dim3(64), 0, st, b.quads, b.qcount, c, b.persp);
-    // four workgroups per frame, 32 quads per workgroup and round (a frame of the benchmark scene has about 60)
-    if (S * S <= 9 * 64)
-        hipLaunchKernelGGL(k_identify<9>, dim3(B, 4), dim3(64 * kIdWaves), lds, st, b.graySrc, b.graySrcC, b.quads, b.qcount, b.dict, b.persp, c);
-    else
-        hipLaunchKernelGGL(k_identify<16>, dim3(B, 4), dim3(64 * kIdWaves), lds, st, b.graySrc, b.graySrcC, b.quads, b.qcount, b.dict, b.persp, c);
+    // As the reference detector does, only the candidates the grouping of near-duplicates selects are identified, and
+    // the other members of a group only when its representative is not a marker: a marker is found at every threshold
+    // scale and as an inner and an outer border, so a frame has several times as many candidates as groups, and the
+    // bit sampling is bound by the scattered reads of the frame (one 64-byte sector per sample).
+    auto run = [&](int pass, int gridY) {
+        if (S * S <= 9 * 64)
+            hipLaunchKernelGGL(k_identify<9>, dim3(B, gridY), dim3(64 * kIdWaves), lds, st, b.graySrc, b.graySrcC, b.quads, b.qcount, b.dict,
+                               b.persp, c, b.idList, b.idCount, pass);
+        else
+            hipLaunchKernelGGL(k_identify<16>, dim3(B, gridY), dim3(64 * kIdWaves), lds, st, b.graySrc, b.graySrcC, b.quads, b.qcount, b.dict,
+                               b.persp, c, b.idList, b.idCount, pass);
+    };
+    if (b.identifyAll) {
+        run(0, 4);  // (four workgroups per frame, 32 quads per workgroup and round)
+        return;
+    }
+    launch_group(c, b, B, st);
+    run(1, 2);  // (two workgroups per frame: the lists are short; smaller batches or more waves were slower)
+    run(2, 2);
 }
 
 }  // namespace camsync

@@ -89,12 +89,18 @@ __device__ bool marker_in_marker(const float* m1, const float* m2) {
 // scales) or few frames, a frame's chain of LDS round trips is the whole stage's time and four wavefronts share it.
 constexpr int kGroupRound = 16;  // candidates whose pair tests are laid out before thread 0 replays them
 
-template <int NQ, int NT>
+// MODE 0: everything in one launch (every candidate has been identified: the debug path).  MODE 1: order and grouping
+// only; lists what the identification has to look at and keeps the order, the selection flags and the fall-back
+// relation in `state` ([B][3][kQuadCap] shorts).  MODE 2: the rest (containment, acceptance, outputs) from that state
+// and the identification's results.
+template <int NQ, int NT, int MODE>
 __global__ __launch_bounds__(NT) void k_select(const QuadRec* __restrict__ quads, const int* __restrict__ qcount,
                                                DetCfg cfg, int32_t* __restrict__ outIds, float* __restrict__ outCorners, float* __restrict__ rawCorners,
                                                int32_t* __restrict__ outCounts, float* __restrict__ outRejected,
                                                int32_t* __restrict__ outRejCounts, MarkerRec* __restrict__ markers,
-                                               unsigned int markerCap, Counters* __restrict__ ctr) {
+                                               unsigned int markerCap, Counters* __restrict__ ctr,
+                                               uint32_t* __restrict__ idList, int* __restrict__ idCount, int16_t* __restrict__ state) {
+    constexpr bool GROUP_ONLY = MODE == 1;
     constexpr int NW = NT / 64;       // wavefronts
     constexpr int NB = NQ / 64;       // blocks of 64 candidates
     constexpr int PER = (NQ + NT - 1) / NT;  // candidates per thread
@@ -111,6 +117,8 @@ __global__ __launch_bounds__(NT) void k_select(const QuadRec* __restrict__ quads
     __shared__ uint8_t s_acc[NQ], s_was[NQ], s_seen[NQ];
     __shared__ short s_use[NQ];       // candidate whose corners/id are reported for a selected entry
     __shared__ int s_nGroups, s_nSel;
+    __shared__ short s_orig[NQ];      // index of the sorted candidate in the frame's quad list
+    __shared__ int s_nList[2];
     __shared__ unsigned long long s_close[kGroupRound][NB];  // per candidate of the round and block: the later candidates close to it
     __shared__ uint32_t s_closeBlocks[kGroupRound];            // ... and which blocks have any
 
@@ -121,10 +129,27 @@ __global__ __launch_bounds__(NT) void k_select(const QuadRec* __restrict__ quads
     const QuadRec* __restrict__ Q = quads + (size_t)f * kQuadCap;
 
     if (n == 0) {
-        if (tid == 0) { outCounts[f] = 0; outRejCounts[f] = 0; }
+        if (tid == 0) {
+            if (GROUP_ONLY) { idCount[2 * f] = 0; idCount[2 * f + 1] = 0; }
+            else { outCounts[f] = 0; outRejCounts[f] = 0; }
+        }
         return;
     }
 
+    int16_t* const st = state + (size_t)f * 3 * kQuadCap;  // [0]: quad index of the sorted candidate, [1]: selected, [2]: fall-back of
+    if (MODE == 2) {
+        for (int r = tid; r < n; r += NT) {
+            const int i = st[r];
+#pragma unroll
+            for (int k = 0; k < 8; k++) s_c[r][k] = (float)Q[i].c[k];
+            s_id[r] = (short)Q[i].id;
+            s_rot[r] = (uint8_t)Q[i].rot;
+            s_valid[r] = (uint8_t)Q[i].valid;
+            s_isSel[r] = (uint8_t)st[kQuadCap + r];
+            s_closeOf[r] = st[2 * kQuadCap + r];
+        }
+        __syncthreads();
+    } else {
     // ---- order: rank by (perimeter desc, scale asc, scanKey desc) ----
     // perimeter needs the corners first
     for (int i = tid; i < n; i += NT) {
@@ -171,7 +196,9 @@ __global__ __launch_bounds__(NT) void k_select(const QuadRec* __restrict__ quads
         s_id[r] = (short)Q[i].id;
         s_rot[r] = (uint8_t)Q[i].rot;
         s_valid[r] = (uint8_t)Q[i].valid;
+        s_orig[r] = (short)i;
     }
+    if (tid == 0) s_nList[0] = s_nList[1] = 0;
     __syncthreads();
     const float rate = cfg.minMarkerDistanceRate;
     for (int i = tid; i < n; i += NT) {
@@ -303,6 +330,24 @@ __global__ __launch_bounds__(NT) void k_select(const QuadRec* __restrict__ quads
         }
     }
     __syncthreads();
+
+    }
+    if (GROUP_ONLY) {
+        // what the identification has to look at: the selected candidates (pass 1), and the fall-backs of each with
+        // their representative (pass 2, skipped for representatives that pass 1 identifies); any order
+        uint32_t* const list = idList + (size_t)f * kQuadCap;
+        for (int i = tid; i < n; i += NT) {
+            st[i] = s_orig[i];
+            st[kQuadCap + i] = s_isSel[i];
+            st[2 * kQuadCap + i] = s_closeOf[i];
+            if (s_isSel[i]) list[atomicAdd(&s_nList[0], 1)] = (uint32_t)(uint16_t)s_orig[i] | 0xFFFF0000u;
+            const int c = s_closeOf[i];
+            if (c >= 0) list[kQuadCap - 1 - atomicAdd(&s_nList[1], 1)] = (uint32_t)(uint16_t)s_orig[i] | ((uint32_t)(uint16_t)s_orig[c] << 16);
+        }
+        __syncthreads();
+        if (tid == 0) { idCount[2 * f] = s_nList[0]; idCount[2 * f + 1] = s_nList[1]; }
+        return;
+    }
 
     // ---- selected list (ascending): positions by ballot, 64 candidates at a time, on the first wavefront ----
     if (wave == 0) {
@@ -469,17 +514,30 @@ void launch_export_markers(const DetBuffers& b, int B, int maxMarkers, int32_t* 
                        dIds, dCorners, dCounts);
 }
 
-void launch_select(const DetCfg& c, const DetBuffers& b, int B, hipStream_t st) {
+namespace {
+
+template <int MODE>
+void launch_select_kernels(const DetCfg& c, const DetBuffers& b, int B, hipStream_t st) {
     // frames with up to 256 candidates: one wavefront per frame when there are frames enough to fill the chip that way,
     // four otherwise (latency of a small batch); frames with more candidates always get four
     if (B >= 1024)
-        hipLaunchKernelGGL((k_select<256, 64>), dim3(B), dim3(64), 0, st, b.quads, b.qcount, c, b.outIds, b.outCorners, b.rawCorners,
-                           b.outCounts, b.outRejected, b.outRejCounts, b.markers, b.markerCap, b.counters);
+        hipLaunchKernelGGL((k_select<256, 64, MODE>), dim3(B), dim3(64), 0, st, b.quads, b.qcount, c, b.outIds, b.outCorners, b.rawCorners,
+                           b.outCounts, b.outRejected, b.outRejCounts, b.markers, b.markerCap, b.counters, b.idList, b.idCount, b.selState);
     else
-        hipLaunchKernelGGL((k_select<256, 256>), dim3(B), dim3(256), 0, st, b.quads, b.qcount, c, b.outIds, b.outCorners, b.rawCorners,
-                           b.outCounts, b.outRejected, b.outRejCounts, b.markers, b.markerCap, b.counters);
-    hipLaunchKernelGGL((k_select<kQuadCap, 256>), dim3(B), dim3(256), 0, st, b.quads, b.qcount, c, b.outIds, b.outCorners, b.rawCorners,
-                       b.outCounts, b.outRejected, b.outRejCounts, b.markers, b.markerCap, b.counters);
+        hipLaunchKernelGGL((k_select<256, 256, MODE>), dim3(B), dim3(256), 0, st, b.quads, b.qcount, c, b.outIds, b.outCorners, b.rawCorners,
+                           b.outCounts, b.outRejected, b.outRejCounts, b.markers, b.markerCap, b.counters, b.idList, b.idCount, b.selState);
+    hipLaunchKernelGGL((k_select<kQuadCap, 256, MODE>), dim3(B), dim3(256), 0, st, b.quads, b.qcount, c, b.outIds, b.outCorners, b.rawCorners,
+                       b.outCounts, b.outRejected, b.outRejCounts, b.markers, b.markerCap, b.counters, b.idList, b.idCount, b.selState);
 }
+
+}  // namespace
+
+void launch_select(const DetCfg& c, const DetBuffers& b, int B, hipStream_t st) {
+    if (b.identifyAll) launch_select_kernels<0>(c, b, B, st);
+    else launch_select_kernels<2>(c, b, B, st);  // (launch_group has run: launch_identify)
+}
+
+// The grouping half alone, before the identification: lists the candidates that can be asked for (DetBuffers::idList).
+void launch_group(const DetCfg& c, const DetBuffers& b, int B, hipStream_t st) { launch_select_kernels<1>(c, b, B, st); }
 
 }  // namespace camsync

@@ -166,6 +166,10 @@ int camsync_debug_points(camsync_ctx* ctx, int frame, int max_points, int32_t* x
  * camsync_debug_restore_capacity puts the allocated capacities back. */
 int camsync_debug_limit_capacity(camsync_ctx* ctx, unsigned int contours, unsigned int points, unsigned int tasks);
 int camsync_debug_restore_capacity(camsync_ctx* ctx);
+/* The pipeline identifies only the quad candidates the selection can ask for (as the reference detector does: the
+ * representative of each group of near-duplicates, its fall-backs only when it is not a marker).  on != 0 makes the
+ * following calls identify every candidate, so that camsync_debug_quads reports an id for each. */
+int camsync_debug_identify_all(camsync_ctx* ctx, int on);
 
 /* ---- pose ----------------------------------------------------------- */
 

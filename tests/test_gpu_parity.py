@@ -132,7 +132,14 @@ def _oracle_quads(gray):
 @pytest.mark.parametrize("name", ["pic_1.png", "pic_2.png"])
 def test_quads_bit_exact(ctx, name):
     bgr = _data.load_bgr(name)
-    ctx.detect(bgr)
+    plain = ctx.detect(bgr)
+    ctx.debug_identify_all(True)  # (the pipeline identifies only the candidates the selection can ask for)
+    try:
+        everything = ctx.detect(bgr)
+    finally:
+        ctx.debug_identify_all(False)
+    for a, b in zip(plain, everything):
+        assert np.array_equal(a, b)  # identifying all candidates changes nothing in the outputs
     d = ctx.debug_quads(0)
     got = set((int(s), int(n)) + tuple(int(v) for v in c.ravel())
               for s, n, c in zip(d["scale"], d["contour_len"], d["corners"]))
