@@ -260,3 +260,47 @@ def test_page_locked_frame_buffers_give_the_same_result():
     for a, b in zip(want, got):
         assert np.array_equal(a, b)
     pinned.close()
+
+
+def test_fall_back_candidate_when_the_representative_is_no_marker():
+    """A thin black ring close around a marker: the ring's outer quad is the largest of the group of near-duplicates
+    (so it is the one selected) and is no marker; the detector then falls back to the marker's own quad.  The pipeline
+    identifies fall-backs only in that case (second identification pass): same result as identifying everything, and
+    as the oracle."""
+    from cameracalibration_amd._dict4x4_50 import CODES
+    img = np.full((480, 640), 235, np.uint8)
+    cell, x0, y0, mid = 20, 240, 160, 23
+    bits = [(int(CODES[mid]) >> (15 - k)) & 1 for k in range(16)]
+    img[y0:y0 + 6 * cell, x0:x0 + 6 * cell] = 20
+    for k, bit in enumerate(bits):
+        if bit:
+            r, c = divmod(k, 4)
+            img[y0 + (1 + r) * cell:y0 + (2 + r) * cell, x0 + (1 + c) * cell:x0 + (2 + c) * cell] = 235
+    gap, t = 14, 5  # white gap, then a ring t pixels thick
+    o = gap + t
+    ring = np.zeros_like(img, bool)
+    ring[y0 - o:y0 + 6 * cell + o, x0 - o:x0 + 6 * cell + o] = True
+    ring[y0 - gap:y0 + 6 * cell + gap, x0 - gap:x0 + 6 * cell + gap] = False
+    img[ring] = 20
+    bgr = np.repeat(img[:, :, None], 3, axis=2)
+    ctx = _hip.Context(480, 640, 1)
+    plain = ctx.detect(bgr)
+    ctx.debug_identify_all(True)
+    try:
+        everything = ctx.detect(bgr)
+        d = ctx.debug_quads(0)
+    finally:
+        ctx.debug_identify_all(False)
+    for a, b in zip(plain, everything):
+        assert np.array_equal(a, b)
+    n = int(plain[2][0])
+    assert plain[0][0, :n].tolist() == [mid]
+    _same_as_oracle(ctx, bgr[None])
+    # the scene does what it is meant to: an unidentified quad larger than, and close to, the identified one
+    per = lambda c: float(np.linalg.norm(c - np.roll(c, -1, axis=0), axis=1).sum())
+    valid = [c for c, i in zip(d["corners"], d["id"]) if int(i) == mid]
+    assert valid
+    v = max(valid, key=per)
+    close_bigger = [c for c, i in zip(d["corners"], d["id"]) if int(i) < 0 and per(c) > per(v)
+                    and np.linalg.norm(c - v, axis=1).mean() < 0.125 * per(v)]
+    assert close_bigger
