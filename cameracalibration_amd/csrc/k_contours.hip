@@ -410,22 +410,16 @@ __device__ __forceinline__ uint32_t pack_state(int x, int y, int sdir) { return 
 // the predecessor is found by the same sweep run clockwise.  T is a bijection, a border is one of its cycles,
 // and OpenCV's contour is the list of pixels along the cycle from the start state.
 //
-// Decide pass: two lanes share a border.  One applies T from the start state, the other T^-1, in lock-step,
-// until they hold the same state (the cycle has been covered: length = sum of the two counts) or one of
-// them meets a crack with a smaller raster key (not the canonical start) or the length bound is exceeded.
-// That halves the longest dependent chain.  Both leave a checkpoint state every kCkStride points.
+// Because T is a bijection a border can be entered anywhere: the long borders are followed in segments from seed to
+// seed (k_seg_walk below), which makes the longest dependent chain one segment instead of one border; the segments'
+// records are linked and the start rule applied afterwards (k_seg_link, k_resolve).
 //
-// Store pass: an accepted border is cut at the checkpoints into independent tasks of at most kCkStride
-// points (StoreTask), so writing the points of a long border is spread over many lanes.
-//
-// Both kernels are persistent; every lane follows its border inside a private LDS window of its bit plane:
-// 2 x 2 half-blocks (32 pixels x 16 rows, 64 bytes each) = 64 columns x 32 rows, addressed toroidally (row
-// y & 31, word (x >> 5) & 1), so shifting the window by one half-block only loads the half-blocks that are new.
-// A step then costs three LDS reads instead of dependent trips to L2/HBM, and the global traffic is whole
-// 64-byte pieces that are fully used.  When any lane of the wave is about to leave its window every lane
-// close to its edge re-centres, which keeps the wave convergent.  Lanes that finish fetch new work from a queue.
-// The window is 2 x 2 pieces of 32 columns x kPieceRows rows (a piece = kPieceRows consecutive words of a
-// plane block), addressed toroidally: 64 columns x 2 kPieceRows rows, 2 kPieceRows x 8 bytes of LDS per lane.
+// The followers are persistent; every lane follows its border inside a private LDS window of its bit plane: 2 x 2
+// pieces of 32 columns x kPieceRows rows (a piece = kPieceRows consecutive words of a plane block), 64 columns x
+// 2 kPieceRows rows, addressed toroidally (row y mod 2 kPieceRows, word (x >> 5) & 1), so moving the window by one
+// piece only loads the pieces that are new: 2 kPieceRows x 8 bytes of LDS per lane.  A step then costs three LDS reads
+// instead of dependent trips to L2/HBM.  Windows are moved in the followers' service phases, for all lanes that are
+// close to an edge at once; lanes that finish take new work from a queue.
 constexpr int kPL = 3;                       // log2(rows per piece): 8-row pieces, 8 KiB of LDS per wavefront
 constexpr int kPieceRows = 1 << kPL;
 constexpr int kWinRows = 2 * kPieceRows;
