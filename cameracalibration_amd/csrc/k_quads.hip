@@ -67,7 +67,8 @@ __global__ __launch_bounds__(64) void k_quad_fit(const ContourRec* __restrict__ 
         int pos = 0, rs = 0;
         bool le_eps = false;
         for (int it = 0; it < 3; it++) {
-            pos = (pos + rs) % n;
+            pos += rs;  // (both below n: one conditional subtraction instead of a division)
+            if (pos >= n) pos -= n;
             const IPt sp = unpack_pt(P(pos));
             uint32_t bd = 0, bj = 0xFFFFFFFFu;
             for (int j = 1 + lane; j < n; j += 64) {
@@ -87,8 +88,9 @@ __global__ __launch_bounds__(64) void k_quad_fit(const ContourRec* __restrict__ 
         int top = 0, cnt = 0;
         bool reject = false;
         if (!le_eps) {
-            const int a = pos % n;
-            const int b = (rs + a) % n;
+            const int a = pos;  // (0 <= pos, rs < n)
+            int b = rs + a;
+            if (b >= n) b -= n;
             if (lane == 0) {
                 s_stack[0][0] = b; s_stack[0][1] = a;  // right slice
                 s_stack[1][0] = a; s_stack[1][1] = b;  // slice
