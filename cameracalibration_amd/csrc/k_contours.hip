@@ -1066,7 +1066,11 @@ __global__ __launch_bounds__(64) void k_seg_walk(const uint32_t* __restrict__ pl
     const unsigned int nCandWaves = (gridDim.x + 3u) / 4u;
     const bool candFirst = (blockIdx.x & 3u) == 0u;
     if (candFirst) seg_walk_items<true>(planes, cfg, seeds, seedCap, candLong, candCap, seg, segCap, chain, ctr, tile, blockIdx.x >> 2, nCandWaves);
-    seg_walk_items<false>(planes, cfg, seeds, seedCap, candLong, candCap, seg, segCap, chain, ctr, tile, blockIdx.x, gridDim.x);
+    // the seeds' static batches go to the other waves first: with little work (a frame or a few) the waves that start
+    // on the candidates then have no seeds of their own, and a frame's two longest chains run side by side
+    const unsigned int nOther = gridDim.x - nCandWaves;
+    const unsigned int seedWave = candFirst ? nOther + (blockIdx.x >> 2) : (blockIdx.x >> 2) * 3u + (blockIdx.x & 3u) - 1u;
+    seg_walk_items<false>(planes, cfg, seeds, seedCap, candLong, candCap, seg, segCap, chain, ctr, tile, seedWave, gridDim.x);
     if (!candFirst) seg_walk_items<true>(planes, cfg, seeds, seedCap, candLong, candCap, seg, segCap, chain, ctr, tile, nCandWaves, nCandWaves);
 }
 
