@@ -86,10 +86,10 @@ __device__ __forceinline__ RawRow issue_row(const uint8_t* __restrict__ in, int 
 // Written so that the compiler keeps that form: the base goes through an empty asm as a pointer to global memory
 // (else it re-associates base + offset and hoists the lane part as a 64-bit lane address), and so does the lane
 // offset (widened to 64 bits outside the row loop it no longer looks like a 32-bit offset).
-__device__ __forceinline__ RawRow issue_row3(const uint8_t* __restrict__ in, size_t rowOff, uint32_t laneByte) {
+__device__ __forceinline__ RawRow issue_row3(const uint8_t* __restrict__ in, size_t rowByte_, uint32_t laneByte) {
     using GBytes = const __attribute__((address_space(1))) uint8_t*;
     using GWords = const __attribute__((address_space(1))) uint64_t*;
-    const uint64_t rowByte = rowOff * 3;
+    const uint64_t rowByte = rowByte_;  // byte offset of the row in the input (3 x its pixel offset)
     // (the builtin returns int: without the casts the low half would be sign-extended over the high one)
     const uint32_t rowLo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)rowByte);
     const uint32_t rowHi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(rowByte >> 32));
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(TPB) void k_gray_thresh3(const uint8_t* __restrict_
     const bool fullOut = MODE ? inOut : inOut && (xbase + 7 < W) && aligned;
     // MODE 1: byte offset of the lane's (clamped) group in a row, see issue_row3
     const uint32_t laneByte = (uint32_t)(min(max(xbase, 0), W - 8) * 3);
-    auto issue = [&](size_t rowOff) { return MODE == 1 ? issue_row3(in, rowOff, laneByte) : issue_row(in, C, W, rowOff, aligned ? xbase : 0); };
+    auto issue = [&](size_t rowOff) { return MODE == 1 ? issue_row3(in, rowOff * 3, laneByte) : issue_row(in, C, W, rowOff, aligned ? xbase : 0); };
     constexpr int K0 = (2 * R0 + 1) * (2 * R0 + 1), K1 = (2 * R1 + 1) * (2 * R1 + 1), K2 = (2 * R2 + 1) * (2 * R2 + 1);
     const int c0 = ((2 * idelta - 1) * K0 + 1) >> 1, c1 = ((2 * idelta - 1) * K1 + 1) >> 1, c2 = ((2 * idelta - 1) * K2 + 1) >> 1;
 
@@ -382,29 +382,38 @@ __global__ __launch_bounds__(TPB) void k_gray_thresh3(const uint8_t* __restrict_
     RawRow pend[UNR];
 #pragma unroll
     for (int k = 0; k < UNR; k++) pend[k] = issue(rowOffOf(y0 + RMAX + k));
+    // the next row to fetch and its offset, kept by addition (a 64-bit multiply per row otherwise)
+    int rowNext = y0 + RMAX + UNR;
+    size_t offNext = rowOffOf(rowNext) * (MODE == 1 ? 3 : 1);  // (MODE 1: in bytes)
     // one row; j = its place in the group (a compile-time constant, so that A and pend are registers)
-    auto do_row = [&](const int y, auto jc) {
+    // (sy = slot(y): the ring slots of the rows a step reads follow from it by additions -- as remainders of a division
+    // by RING they were four scalar multiply-high sequences per row)
+    auto wrap = [](int v) { return v >= RING ? v - RING : v; };
+    auto do_row = [&](const int y, const int sy, auto jc) {
         constexpr int j = decltype(jc)::value;
         A[RMAX + j] = aligned ? gray_of(pend[j], C, W, xbase) : load_gray8(in, C, W, rowOffOf(y + RMAX), xbase, false);
-        pend[j] = issue(rowOffOf(y + RMAX + UNR));
+        // row y + RMAX + UNR, clamped to the last row
+        pend[j] = MODE == 1 ? issue_row3(in, offNext, laneByte) : issue(offNext);
+        if (rowNext < H - 1) offNext += MODE == 1 ? (size_t)W * 3 : (size_t)W;
+        rowNext++;
 
         uint32_t a[4], b[4];
         // every window takes in the row r_k below the centre (registers) and drops the row r_k + 1 above it (ring)
         widen8(A[R2 + j], a);
-        widen8(*reinterpret_cast<const uint2*>(&ring[slot(y - R2 - 1)][PX * tid]), b);
+        widen8(*reinterpret_cast<const uint2*>(&ring[wrap(sy + (4 * RING - R2 - 1) % RING)][PX * tid]), b);
 #pragma unroll
         for (int i = 0; i < 4; i++) V2[i] = V2[i] + a[i] - b[i];
         widen8(A[R1 + j], a);
-        widen8(*reinterpret_cast<const uint2*>(&ring[slot(y - R1 - 1)][PX * tid]), b);
+        widen8(*reinterpret_cast<const uint2*>(&ring[wrap(sy + (4 * RING - R1 - 1) % RING)][PX * tid]), b);
 #pragma unroll
         for (int i = 0; i < 4; i++) V1[i] = V1[i] + a[i] - b[i];
         widen8(A[R0 + j], a);
-        widen8(*reinterpret_cast<const uint2*>(&ring[slot(y - R0 - 1)][PX * tid]), b);
+        widen8(*reinterpret_cast<const uint2*>(&ring[wrap(sy + (4 * RING - R0 - 1) % RING)][PX * tid]), b);
 #pragma unroll
         for (int i = 0; i < 4; i++) V0[i] = V0[i] + a[i] - b[i];
         const uint2 cen = A[j];  // row y
         // row y replaces row y-RMAX-1 in the ring (read just above)
-        *reinterpret_cast<uint2*>(&ring[slot(y)][PX * tid]) = cen;
+        *reinterpret_cast<uint2*>(&ring[sy][PX * tid]) = cen;
 
         // exchange vertical sums (single wavefront: the barrier only orders this wave's LDS traffic)
         wave_lds_sync();
@@ -459,19 +468,20 @@ __global__ __launch_bounds__(TPB) void k_gray_thresh3(const uint8_t* __restrict_
     };
     // whole groups without an early exit (an exit between the rows of a group makes the compiler assume that
     // the loads of the first row are the youngest in flight, and wait for all of them at the top of the loop)
-    int yg = y0;
+    int yg = y0, sg = slot(y0);
     for (; yg + UNR <= y1; yg += UNR) {
-        do_row(yg, std::integral_constant<int, 0>());
-        do_row(yg + 1, std::integral_constant<int, 1>());
-        do_row(yg + 2, std::integral_constant<int, 2>());
-        do_row(yg + 3, std::integral_constant<int, 3>());
+        do_row(yg, sg, std::integral_constant<int, 0>());
+        do_row(yg + 1, wrap(sg + 1), std::integral_constant<int, 1>());
+        do_row(yg + 2, wrap(sg + 2), std::integral_constant<int, 2>());
+        do_row(yg + 3, wrap(sg + 3), std::integral_constant<int, 3>());
 #pragma unroll
         for (int k = 0; k < RMAX; k++) A[k] = A[k + UNR];
+        sg = wrap(sg + UNR);
     }
     static_assert(UNR == 4, "the row groups are written out for four rows");
-    if (yg < y1) do_row(yg, std::integral_constant<int, 0>());
-    if (yg + 1 < y1) do_row(yg + 1, std::integral_constant<int, 1>());
-    if (yg + 2 < y1) do_row(yg + 2, std::integral_constant<int, 2>());
+    if (yg < y1) do_row(yg, sg, std::integral_constant<int, 0>());
+    if (yg + 1 < y1) do_row(yg + 1, wrap(sg + 1), std::integral_constant<int, 1>());
+    if (yg + 2 < y1) do_row(yg + 2, wrap(sg + 2), std::integral_constant<int, 2>());
     // the band that ends the image also writes the zero rows that pad the last block row
     if (y1 == H) {
         for (int yy = H; yy < plane_hb(H) * 32; yy++) {
