@@ -641,7 +641,10 @@ __device__ __forceinline__ void adopt_orphans(WaveAlloc& slotA, WaveAlloc& taskA
 // takes the next one from the wave's batch, instead of the wave waiting for its slowest lane every round
 // (which made 94 % of the wave-steps idle).  Each step advances the candidate's forward tracer and, in
 // lock-step, a tracer walking the border the other way round; both look for a crack with a smaller key.
-constexpr int kShortBudget = 48;
+// steps a candidate gets here before it goes to the long list (measured on the bench scene, ms of the whole border
+// stage: 8: 5.10, 16: 4.34, 20: 4.31, 24: 4.33, 32: 4.43, 48: 4.56, 64: 4.79 -- the 5 % of the candidates that use the
+// whole budget cost a third of this pass's iterations at 48, and the segment followers take them over for less)
+constexpr int kShortBudget = 24;
 constexpr unsigned int kWalkBatch = 128, kResolveBatch = 64;
 constexpr unsigned int kShortBatch = 256, kShortPoolBlock = 2048, kLongStage = 64;
 
