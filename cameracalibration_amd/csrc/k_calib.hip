@@ -45,6 +45,9 @@ __device__ __forceinline__ double lane_bcast(double v, int src) {
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
+// Wait until this wave's outstanding vector memory operations (the write-through record stores) are acknowledged.
+__device__ __forceinline__ void stores_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 constexpr int kLmWaves = 4;       // views in flight per workgroup
 constexpr int kLmRecord = 160;    // doubles per partial record (>= NI^2 + NI + 3)
 constexpr int kLmGroup = 32;      // records summed per level of the final reduction (at most kLmGroup^2 workgroups)
@@ -298,14 +301,18 @@ __global__ __launch_bounds__(64 * kLmWaves) void k_calib_lm(CalibState s, int mo
 #pragma unroll
         for (int w = 1; w < kLmWaves; w++) t += comb[w][tid];
         __hip_atomic_store(s.partial + (size_t)blockIdx.x * kLmRecord + tid, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        stores_done();
     }
     // Two levels, kLmGroup records each, so that the loads of a level are all in flight at once: the last workgroup
     // of a group sums the group's records, the last of those sums the groups.
     const unsigned int group = blockIdx.x / kLmGroup, nGroups = (gridDim.x + kLmGroup - 1) / kLmGroup;
     const unsigned int inGroup = min((unsigned int)kLmGroup, gridDim.x - group * kLmGroup);
     double* const groupRec = s.partial + (size_t)gridDim.x * kLmRecord;
-    // The records cross workgroups as device-scope atomic stores and loads (they go to memory, past this XCD's L2)
-    // and __syncthreads() waits for the stores: no release fence, which would write back the whole L2 per workgroup.
+    // The records cross workgroups as device-scope atomic stores and loads (write-through / read-through past this
+    // XCD's L2).  Every thread waits for its own record stores to be acknowledged (stores_done) before the barrier,
+    // so all of the workgroup's record is at the device's point of coherence before thread 0 takes its ticket; the
+    // reader's loads are issued after its ticket's value has come back.  That orders the hand-off without a release
+    // fence, which would write back the XCD's whole L2 per workgroup (40 us per launch).
     __syncthreads();
     if (tid == 0) lastBlock = atomicAdd(s.ticket + 1 + group, 1u) == inGroup - 1 ? 1u : 0u;
     __syncthreads();
@@ -319,6 +326,7 @@ __global__ __launch_bounds__(64 * kLmWaves) void k_calib_lm(CalibState s, int mo
 #pragma unroll
         for (int i = 1; i < kLmGroup; i++) t += v[i];
         __hip_atomic_store(groupRec + (size_t)group * kLmRecord + tid, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        stores_done();
     }
     __syncthreads();
     if (tid == 0) {

@@ -71,20 +71,38 @@ void jacobi_eigen(const double* A_in, int n, double* w, double* V) {
 /* Solve a symmetric positive semi-definite system through its
  * eigen-decomposition (what cv::solve(DECOMP_SVD / DECOMP_EIG) amounts to
  * for JtJ), truncating singular directions like SVD::backSubst. */
-void solve_sym(const double* A, const double* b, int n, double* x) {
-    std::vector<double> w(n), V((size_t)n * n);
-    jacobi_eigen(A, n, w.data(), V.data());
+struct SymEig {
+    int n;
+    std::vector<double> w, V;
+    double thr;
+};
+
+void sym_eig(const double* A, int n, SymEig& e) {
+    e.n = n;
+    e.w.resize(n);
+    e.V.resize((size_t)n * n);
+    jacobi_eigen(A, n, e.w.data(), e.V.data());
     double thr = 0;
-    for (int i = 0; i < n; i++) thr += fabs(w[i]);
-    thr *= DBL_EPSILON * 2;
+    for (int i = 0; i < n; i++) thr += fabs(e.w[i]);
+    e.thr = thr * (DBL_EPSILON * 2);
+}
+
+void sym_backsub(const SymEig& e, const double* b, double* x) {
+    const int n = e.n;
     for (int i = 0; i < n; i++) x[i] = 0;
     for (int k = 0; k < n; k++) {
-        if (fabs(w[k]) <= thr) continue;
+        if (fabs(e.w[k]) <= e.thr) continue;
         double s = 0;
-        for (int i = 0; i < n; i++) s += V[k * n + i] * b[i];
-        s /= w[k];
-        for (int i = 0; i < n; i++) x[i] += s * V[k * n + i];
+        for (int i = 0; i < n; i++) s += e.V[k * n + i] * b[i];
+        s /= e.w[k];
+        for (int i = 0; i < n; i++) x[i] += s * e.V[k * n + i];
     }
+}
+
+void solve_sym(const double* A, const double* b, int n, double* x) {
+    SymEig e;
+    sym_eig(A, n, e);
+    sym_backsub(e, b, x);
 }
 
 /* 3x3 SVD R = U diag(w) Vt through the eigen-decomposition of RtR. */
@@ -965,14 +983,16 @@ extern "C" double orc_calibrate(const double* obj, const double* img, int V, int
             memcpy(A, &Aee[(size_t)v * 36], sizeof A);
             for (int r = 0; r < 6; r++) A[r * 6 + r] *= 1. + lambda;
             const double* B = &Bie[(size_t)v * NI * 6];
-            /* solve A X = [Bt | g] column by column */
+            /* solve A X = [Bt | g] column by column (one decomposition of A serves every column) */
+            SymEig eA;
+            sym_eig(A, 6, eA);
             for (int c = 0; c < NI; c++) {
                 double bcol[6], x[6];
                 for (int r = 0; r < 6; r++) bcol[r] = B[c * 6 + r];
-                solve_sym(A, bcol, 6, x);
+                sym_backsub(eA, bcol, x);
                 for (int r = 0; r < 6; r++) AinvBt[((size_t)v * 6 + r) * NI + c] = x[r];
             }
-            solve_sym(A, &ge[(size_t)v * 6], 6, &Ainvg[(size_t)v * 6]);
+            sym_backsub(eA, &ge[(size_t)v * 6], &Ainvg[(size_t)v * 6]);
             for (int r = 0; r < NI; r++) {
                 double s = 0;
                 for (int q = 0; q < 6; q++) s += B[r * 6 + q] * Ainvg[(size_t)v * 6 + q];
@@ -1156,13 +1176,15 @@ void orc_calib_accumulate(void* h, double lambda, double* acc) {
         for (int r = 0; r < 6; r++) A[r * 6 + r] *= 1. + lambda;
         double* AinvBt = &s.AinvBt[(size_t)v * 6 * NI];
         double* Ainvg = &s.Ainvg[(size_t)v * 6];
+        SymEig eA;
+        sym_eig(A, 6, eA);
         for (int c = 0; c < NI; c++) {
             double bcol[6], x[6];
             for (int r = 0; r < 6; r++) bcol[r] = B[c * 6 + r];
-            solve_sym(A, bcol, 6, x);
+            sym_backsub(eA, bcol, x);
             for (int r = 0; r < 6; r++) AinvBt[r * NI + c] = x[r];
         }
-        solve_sym(A, g, 6, Ainvg);
+        sym_backsub(eA, g, Ainvg);
         for (int r = 0; r < NI; r++) {
             double sg = 0;
             for (int q = 0; q < 6; q++) sg += B[r * 6 + q] * Ainvg[q];

@@ -105,17 +105,12 @@ def test_multiple_cameras_average():
         processArucoFromMultipleCameras([], moving, cams, [frame])
 
 
-def test_multiple_cameras_batched_equals_the_per_camera_loop():
-    """processArucoFromMultipleCameras runs all cameras as one batch (SURVEY 8(f)1); the reference loops over the
-    cameras (aruco.py:417).  Eight 1080p cameras with distinct intrinsics, one camera that sees nothing and one
-    720p camera: camera poses, filtered positions and the fused marker corners must equal the loop's exactly."""
-    import copy
+def _eight_camera_scene():
+    """Eight 1080p cameras with distinct intrinsics, one camera that sees nothing and one 720p camera looking at the
+    reference's pic_2.png with the reference's Logitec_A calibration (the golden-pose camera, test_aruco.py:329-359)."""
     from cameracalibration_amd import synth
-    from cameracalibration_amd.camera_sync.aruco import (Aruco, getArucosFromPaper, processAruco,
-                                                         processArucoFromMultipleCameras)
     from cameracalibration_amd.camera_sync.camera import Camera
 
-    K, _ = _data.calibration("Logitec_robot_1920-1080_10.npz")
     frames, cams = [], []
     for i in range(8):
         cam = Camera("Logitec_robot", -1, focus=10, resolution=(1920, 1080))
@@ -129,13 +124,33 @@ def test_multiple_cameras_batched_equals_the_per_camera_loop():
     frames.append(np.full((1080, 1920, 3), 90, np.uint8))            # sees nothing: skipped
     cams.append(Camera("Logitec_A", -1, focus=0, resolution=(1280, 720)))
     frames.append(_data.load_bgr("pic_2.png"))                        # another resolution: its own batch
+    return frames, cams
+
+
+def _rt_matrix(rvec, tvec):
+    m = np.eye(4)
+    m[:3, :3] = _oracle.rodrigues_vec2mat(rvec)
+    m[:3, 3] = np.asarray(tvec).ravel()
+    return m
+
+
+def test_multiple_cameras_batched_equals_the_per_camera_loop():
+    """processArucoFromMultipleCameras runs all cameras as one batch (SURVEY 8(f)1); the reference loops over the
+    cameras (aruco.py:417).  Camera poses, filtered positions and the fused marker corners must (1) equal the
+    per-camera loop's exactly and (2) equal aruco.py:407-470 restated here in numpy over the CPU oracle's detection,
+    solvePnP and IPPE_SQUARE; the pic_2 / Logitec_A camera must also land on the reference's golden pose."""
+    import copy
+    from cameracalibration_amd.camera_sync.aruco import (Aruco, getArucosFromPaper, processAruco,
+                                                         processArucoFromMultipleCameras)
+
+    frames, cams = _eight_camera_scene()
     sheet = getArucosFromPaper(1)
     fixed = [sheet[i] for i in (10, 11, 14, 15)]
 
-    def run(batched):
+    def run(batched, sets=2):
         cs = copy.deepcopy(cams)
         moving = {k: copy.deepcopy(sheet[k]) for k in (12, 13)}
-        for _ in range(2):  # twice: the low-pass filters carry state from the first set to the second
+        for _ in range(sets):  # twice: the low-pass filters carry state from the first set to the second
             if batched:
                 processArucoFromMultipleCameras(fixed, moving, cs, frames, getMetrics=True)
             else:
@@ -169,6 +184,46 @@ def test_multiple_cameras_batched_equals_the_per_camera_loop():
         want = np.array([c.coords for c in ml[k].corners], float)
         assert np.array_equal(got, want)
         assert not np.array_equal(got, np.array([c.coords for c in sheet[k].corners], float))
+
+    # ---- against the oracle and the reference's golden pose: one set of frames from fresh state ----
+    c1, m1 = run(True, sets=1)
+    G = _data.goldens()["pic_2_pose"]
+    seen = {}
+    for cam, f, got in zip(cams, frames, c1):
+        oids, ocor, _ = _oracle.detect(f)
+        found = {int(i): c for i, c in zip(oids, ocor)}
+        obj = [p for a in fixed if a.id in found for p in a.getCornersAsList()]
+        img = [p for a in fixed if a.id in found for p in found[a.id]]
+        if len(img) < 4:
+            assert not hasattr(got, "world2cam")
+            continue
+        ok, orv, otv = _oracle.solve_pnp(np.array(obj, np.float32), np.array(img, np.float32), cam.mtx, cam.dist)
+        assert ok
+        w2c = _rt_matrix(orv, otv)
+        assert np.allclose(got.world2cam.transf_mat[:3, :3], w2c[:3, :3], rtol=0, atol=1e-6)
+        assert np.allclose(got.world2cam.transf_mat[:3, 3], w2c[:3, 3], rtol=1e-6, atol=1e-6)
+        c2w = np.linalg.inv(w2c)
+        assert np.allclose(got.world_position.coords, 0.4 * c2w[:3, 3], rtol=1e-6, atol=1e-6)  # low-pass from (0,0,0)
+        if tuple(cam._resolution) == (1280, 720):
+            assert np.allclose(got.world2cam.transf_mat[:3, 3], G["tvec"], atol=1e-4)
+            # the golden rotation is 3.1424 rad > pi: compared as a matrix (Transform keeps the round-tripped rvec)
+            assert np.allclose(got.world2cam.transf_mat[:3, :3], _oracle.rodrigues_vec2mat(G["rvec"]), atol=1e-4)
+        for k in (12, 13):
+            if k not in found:
+                continue
+            size = sheet[k].size
+            ok, mrv, mtv = _oracle.ippe_square(found[k], size, cam.mtx, cam.dist)
+            assert ok
+            a2w = c2w @ _rt_matrix(mrv, mtv)
+            h = size / 2
+            local = np.array([[-h, h, 0, 1], [h, h, 0, 1], [h, -h, 0, 1], [-h, -h, 0, 1.0]])
+            seen.setdefault(k, []).append((a2w @ local.T).T[:, :3])
+    assert set(seen) == {12, 13} and all(len(v) == 9 for v in seen.values())
+    for k, a in m1.items():
+        before = np.array([c.coords for c in sheet[k].corners], float)
+        want = 0.4 * np.mean(seen[k], axis=0) + 0.6 * before
+        got = np.array([c.coords for c in a.corners], float)
+        assert np.allclose(got, want, rtol=0, atol=1e-4), (k, np.abs(got - want).max())  # millimetres
 
 
 def test_batched_additions_equal_per_frame_calls():

@@ -334,6 +334,30 @@ def test_calibrate_vs_oracle(ctx, rational):
     assert abs(K[0, 0] - 1400) < 15 and abs(K[1, 1] - 1400) < 15
 
 
+@pytest.mark.parametrize("V", [200, 2000])
+def test_calibrate_vs_oracle_at_full_size(ctx, V):
+    """BASELINE configs[3]'s real size (2000 views, rational model): 500 workgroups, so the record is summed over
+    workgroups in two levels (k_calib.hip, kLmGroup) -- the path the small cases above never reach; V = 200 crosses the
+    first level only.  Run twice on one context: the tickets of the reduction are reset by the kernel itself."""
+    from cameracalibration_amd import synth
+    obj, img, K0, d0 = synth.calib_views(V=V, seed=42, rational=True)
+    o_rms, oK, odist, orv, otv, oit = orc.calibrate(obj, img, (1920, 1080), rational=True)
+    first = None
+    for rep in range(2):
+        rms, K, dist, rv, tv, iters = ctx.calibrate(obj, img, (1920, 1080), rational=True)
+        assert abs(rms - o_rms) <= 1e-6, (rep, rms, o_rms)
+        assert abs(iters - oit) <= 2, (iters, oit)  # the loop ends when the step is down at rounding level
+        assert np.allclose(K, oK, rtol=1e-5), (K, oK)
+        assert np.allclose(dist, odist, rtol=1e-4, atol=1e-6), (dist, odist)
+        assert np.allclose(rv, orv, rtol=1e-5, atol=1e-6) and np.allclose(tv, otv, rtol=1e-5, atol=1e-6)
+        if first is None:
+            first = (rms, K.copy(), dist.copy(), rv.copy(), tv.copy())
+        else:  # fixed summation order: a repeat is the same to the bit
+            assert rms == first[0] and np.array_equal(K, first[1]) and np.array_equal(dist, first[2])
+            assert np.array_equal(rv, first[3]) and np.array_equal(tv, first[4])
+    assert abs(K[0, 0] - 1400) < 3 and abs(K[1, 1] - 1400) < 3
+
+
 @pytest.mark.parametrize("size", ["1080p", "4k"])
 @pytest.mark.parametrize("channels", [3, 1])
 def test_pipeline_threshold_planes_bit_exact(size, channels):
