@@ -32,19 +32,9 @@ def grow_lattice(points, pattern):
         return None
     D = np.linalg.norm(P[:, None] - P[None], axis=2) + np.eye(K) * 1e18
     best = None
-    for seed in range(min(K, 16)):
-        near = np.argsort(D[seed])[:6]
-        u = P[near[0]] - P[seed]
-        lu = np.linalg.norm(u)
-        v = None
-        for j in near[1:]:
-            w = P[j] - P[seed]
-            lw = np.linalg.norm(w)
-            if abs(np.dot(u, w)) < 0.5 * lu * lw and 0.5 < lw / lu < 2.0:  # roughly perpendicular, similar length
-                v = w
-                break
-        if v is None:
-            continue
+    full = cols * rows
+
+    def grow(seed, u, v):
         coords = {seed: (0, 0)}
         taken = {(0, 0): seed}
         step = {seed: (u, v)}
@@ -67,20 +57,42 @@ def grow_lattice(points, pattern):
                 # perspective and lens distortion change the step slowly: carry the step just taken forward
                 step[j] = ((P[j] - P[i]) * di, vi) if di else (ui, (P[j] - P[i]) * dj)
                 queue.append(j)
-        if best is None or len(taken) > len(best):
-            best = taken
-        if len(taken) >= cols * rows:
-            break
-    if best is None:
+        return taken
+
+    def rectangle(taken):
+        """The cols x rows block of lattice coordinates that is fully populated, as image points, or None."""
+        ii = [c[0] for c in taken]
+        jj = [c[1] for c in taken]
+        for a, b in ((cols, rows), (rows, cols)):
+            for i0 in range(min(ii), max(ii) - a + 2):
+                for j0 in range(min(jj), max(jj) - b + 2):
+                    if all((i0 + i, j0 + j) in taken for i in range(a) for j in range(b)):
+                        G = np.array([[P[taken[(i0 + i, j0 + j)]] for i in range(a)] for j in range(b)])
+                        return G if (a, b) == (cols, rows) else np.transpose(G, (1, 0, 2))
         return None
-    ii = [c[0] for c in best]
-    jj = [c[1] for c in best]
-    for a, b in ((cols, rows), (rows, cols)):
-        for i0 in range(min(ii), max(ii) - a + 2):
-            for j0 in range(min(jj), max(jj) - b + 2):
-                if all((i0 + i, j0 + j) in best for i in range(a) for j in range(b)):
-                    G = np.array([[P[best[(i0 + i, j0 + j)]] for i in range(a)] for j in range(b)])
-                    return G if (a, b) == (cols, rows) else np.transpose(G, (1, 0, 2))
+
+    for seed in range(min(K, 16)):
+        # Candidate step pairs from the seed's nearest neighbours, nearest first.  On a board seen at a grazing angle a
+        # diagonal neighbour is nearer than a lattice neighbour; a pair with a diagonal in it reaches every other corner
+        # or numbers the corners in a sheared frame, neither of which fills the pattern's rectangle, so the pairs are
+        # tried until one does.
+        near = np.argsort(D[seed])[:8]
+        pairs = []
+        for a in range(len(near)):
+            u = P[near[a]] - P[seed]
+            lu = np.linalg.norm(u)
+            for b in range(a + 1, len(near)):
+                w = P[near[b]] - P[seed]
+                lw = np.linalg.norm(w)
+                if abs(np.dot(u, w)) < 0.9 * lu * lw and 0.4 < lw / lu < 2.5:
+                    pairs.append((abs(np.dot(u, w)) >= 0.5 * lu * lw or not 0.5 < lw / lu < 2.0, a + b, a, u, w))
+        pairs.sort(key=lambda t: t[:3])  # roughly perpendicular steps of similar length first
+        for _, _, _, u, v in pairs[:16]:
+            taken = grow(seed, u, v)
+            if len(taken) >= full:
+                G = rectangle(taken)
+                if G is not None:
+                    return G
     return None
 
 

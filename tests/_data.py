@@ -33,3 +33,13 @@ def v1_anchor_points(ids=(10, 11, 14, 15)):
         s = 80
         out.append([[x, y, 0], [x + s, y, 0], [x + s, y - s, 0], [x, y - s, 0]])
     return np.array(out, np.float32)
+
+
+def photo_sets():
+    """The reference's other photo sets (copies of /root/reference/pics/...): name -> sorted file names under
+    tests/golden.  `poses` and `robot_calib` are 640x480 JPEGs of the v1 marker sheet, `poses_blender` are 1920x1080
+    Blender renders of it, `calib_blender` are renders of the 8 x 8 chessboard."""
+    out = {}
+    for d in ("poses", "poses_blender", "robot_calib", "calib_blender"):
+        out[d] = [os.path.join(d, f) for f in sorted(os.listdir(os.path.join(GOLDEN, d)))]
+    return out

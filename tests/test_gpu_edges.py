@@ -304,3 +304,36 @@ def test_fall_back_candidate_when_the_representative_is_no_marker():
     close_bigger = [c for c, i in zip(d["corners"], d["id"]) if int(i) < 0 and per(c) > per(v)
                     and np.linalg.norm(c - v, axis=1).mean() < 0.125 * per(v)]
     assert close_bigger
+
+
+@pytest.mark.parametrize("group", ["poses", "robot_calib", "poses_blender"])
+def test_other_reference_photos_match_the_oracle(group):
+    """The reference's other marker-sheet photos (pics/poses, pics/robot_calib: 640x480 JPEGs; pics/blender/poses:
+    1920x1080 renders), each set as one batch: ids and order exact, rejected quads exact, corners <= 1e-3 px against the
+    oracle; and every frame yields the markers of the sheet it shows (tests/test_oracle_goldens.py::EXPECTED_IDS)."""
+    from tests.test_oracle_goldens import EXPECTED_IDS
+    names = _data.photo_sets()[group]
+    frames = np.stack([_data.load_bgr(n) for n in names])
+    ctx = _hip.Context(frames.shape[1], frames.shape[2], len(frames))
+    ids, corners, counts, _, _ = ctx.detect(frames)
+    for b, n in enumerate(names):
+        assert sorted(ids[b, :int(counts[b])].tolist()) == EXPECTED_IDS[n], n
+    _same_as_oracle(ctx, frames)
+    # contours point for point on the busiest frame of the set (textured desk scenes: thousands of borders per scale)
+    h, w = frames.shape[1:3]
+    minp, maxp = int(0.03 * max(h, w)), int(4.0 * max(h, w))
+    one = _hip.Context(h, w, 1)
+    one.detect(frames[-1])
+    d = one.debug_contours(0, cap=262144)
+    pts = one.debug_points(0)
+    want = {}
+    gray = orc.bgr2gray(frames[-1])
+    for s, win in enumerate((3, 13, 23)):
+        for c in orc.find_contours(orc.adaptive_threshold(gray, win)):
+            if minp <= len(c) <= maxp:
+                want[(s, int(c[0][1]) * w + int(c[0][0]), len(c))] = c
+    assert len(d["length"]) == len(want)
+    off = 0
+    for s, k, n in zip(d["scale"].tolist(), d["start_key"].tolist(), d["length"].tolist()):
+        assert np.array_equal(pts[off:off + n], want[(s, k, n)]), (s, k, n)
+        off += n

@@ -124,3 +124,44 @@ def test_dictionary_verified_ids_identify():
         for rot in range(4):
             ok, idv, r, _ = _oracle.identify(img, np.roll(corners, -rot, axis=0))
             assert ok and idv == mid
+
+
+# ---- the reference's other photo sets (pics/poses, pics/blender/poses, pics/robot_calib, pics/blender/calib)
+
+EXPECTED_IDS = {
+    # every photo of pics/poses shows the six big markers of the v1 sheet
+    **{"poses/frame_pose%d.jpg" % i: [10, 11, 12, 13, 14, 15] for i in range(8)},
+    # the Blender renders see part of the sheet or all of it
+    "poses_blender/pose1.png": [10, 11], "poses_blender/pose2.png": [12, 13, 14, 15],
+    "poses_blender/pose3.png": [10, 11, 12, 13, 14, 15],
+    # pics/robot_calib: the whole v1 sheet including its four 27 mm markers, ids 0-3 (aruco.py:126-129)
+    "robot_calib/frame10.jpg": [0, 1, 2, 3, 10, 11, 12, 13, 14, 15], "robot_calib/frame11.jpg": [0, 1, 2, 3],
+    "robot_calib/frame12.jpg": [10, 11, 12, 13, 14, 15], "robot_calib/frame13.jpg": [10, 11, 12, 13, 14, 15],
+}
+
+
+def test_other_reference_photos_show_the_sheet_they_were_taken_of():
+    """No golden corners exist for these photos (nothing in the reference reads them), but the reference says which
+    markers are on the sheet they show (getArucosFromPaper(1), aruco.py:124-136): the oracle must find exactly those
+    ids, no others, each once."""
+    for name, want in EXPECTED_IDS.items():
+        ids, cor, _ = _oracle.detect(_data.load_bgr(name))
+        assert sorted(ids.tolist()) == want, (name, sorted(ids.tolist()))
+
+
+def test_p7_dictionary_ids_0_to_3_are_pinned_by_the_robot_calib_photos():
+    """PIN P7.  SURVEY Appendix B could verify 34 of the 50 dictionary codes from the reference's printable sheets;
+    ids 0-3 were recalled only.  pics/robot_calib/frame10.jpg and frame11.jpg are photos of the v1 sheet, whose four
+    small markers the reference declares to be ids 1, 2, 3, 0 (aruco.py:126-129): with the recalled codes the detector
+    finds four small markers there and identifies them as exactly {0, 1, 2, 3} (exact match, no error correction:
+    DICT_4X4_50's maxCorrectionBits 1 x errorCorrectionRate 0.6 -> 0 bits), the same four in both photos."""
+    for name in ("robot_calib/frame10.jpg", "robot_calib/frame11.jpg"):
+        ids, cor, _ = _oracle.detect(_data.load_bgr(name))
+        small = {int(i): c for i, c in zip(ids, cor) if i < 10}
+        assert sorted(small) == [0, 1, 2, 3], (name, sorted(small))
+        big = [c for i, c in zip(ids, cor) if i >= 10]
+        side = lambda c: float(np.mean(np.linalg.norm(c - np.roll(c, 1, axis=0), axis=1)))  # noqa: E731
+        # 27 mm against 80 mm markers: about a third of the side where both are in view
+        if big:
+            ratio = np.mean([side(c) for c in small.values()]) / np.mean([side(c) for c in big])
+            assert 0.25 < ratio < 0.45, ratio
