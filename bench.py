@@ -31,7 +31,7 @@ ALG_BYTES_PER_PX_K1K3 = 11.0  # + contour extraction 3r
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
-def make_frames(torch, dev, n_frames, H, W, K, pool=32, seed=1234):
+def make_frames(torch, dev, n_frames, H, W, K, pool=256, seed=1234):
     """n_frames synthetic frames [n,H,W,3] u8 on `dev`: `pool` rendered poses of the v1 sheet,
     each frame = pose (i % pool) + its own Gaussian noise (sigma 4, seed per frame block)."""
     from cameracalibration_amd import synth
@@ -209,6 +209,8 @@ def main():
     ap.add_argument("--cpu-sample-1", type=int, default=64, help="frames of the sample timed on ONE CPU thread as well")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--calib-views", type=int, default=2000)
+    ap.add_argument("--poses", type=int, default=256, help="rendered poses the frames cycle through (each frame adds its own noise)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary configurations (4K, photo scene, 8 cameras)")
     args = ap.parse_args()
 
     if args.gpus < 1:
@@ -250,7 +252,7 @@ def main():
     anchors = [10, 11, 14, 15]
     anchor_obj = _data.v1_anchor_points(anchors)
 
-    frames = make_frames(torch, dev, args.frames, H, W, K, seed=1234 + 100000 * rank)
+    frames = make_frames(torch, dev, args.frames, H, W, K, pool=min(args.poses, args.frames), seed=1234 + 100000 * rank)
     B = args.frames
     MM = 16
     d_ids = torch.full((B, MM), -1, dtype=torch.int32, device=dev)
@@ -323,6 +325,7 @@ def main():
     # secondary metric: calibration LM iterations/s (configs[3]); with N > 1 the views are sharded over the ranks and
     # the records are summed by RCCL (torch.distributed "nccl") inside camsync_calibrate_dist
     calib = None
+    calib_inputs = None
     try:
         from cameracalibration_amd import synth
         from cameracalibration_amd.calibrate_dist import calibrate_distributed
@@ -336,6 +339,7 @@ def main():
             t3 = time.perf_counter()
             ctx.calibrate(obj, img, (1920, 1080), rational=True, max_iter=1)
             t4 = time.perf_counter()
+            calib_inputs = (obj, img)
             calib = {"views": args.calib_views, "iters": iters, "iters_per_s": iters / (t2 - t1), "rms_px": rms,
                      "includes": "init (homographies + per-view PnP) + LM",
                      "lm_only_iters_per_s": (iters - 1) / max((t2 - t1) - (t4 - t3), 1e-9) if iters > 1 else None}
@@ -374,7 +378,8 @@ def main():
             "dtype": "u8",
             "data": "synthetic",
             "config": {"workload": f"configs[1]: DICT_4X4_50 detect + anchor PnP, {B} synthetic {W}x{H} BGR frames per GPU, "
-                                   f"6 markers (v1 sheet), 4 anchors, chunk {min(args.chunk, B)}",
+                                   f"6 markers (v1 sheet), 4 anchors, {min(args.poses, B)} rendered poses x per-frame noise "
+                                   f"(sigma 4), chunk {min(args.chunk, B)}",
                        "frames_per_gpu": B, "height": H, "width": W, "parallelism": f"frames sharded x{world}"},
             # `achieved` follows the contract: ALGORITHMIC bytes (8 B/px for gray + 3 thresholds) over the
             # kernel's time.  The fused kernel physically moves far fewer bytes (`physical`): it does not sit at 91 % of
@@ -408,6 +413,26 @@ def main():
             out["check"].update(compare_with_oracle(res, d_ids[:ns].cpu().numpy(), d_cor[:ns].cpu().numpy(), d_cnt[:ns].cpu().numpy(),
                                                     d_ok[:ns].cpu().numpy(), d_rv[:ns].cpu().numpy(), d_tv[:ns].cpu().numpy()))
         out["calib_lm"] = calib
+        if not args.no_cpu and world == 1 and calib_inputs is not None and "error" not in calib:
+            # configs[3] at its real size against the oracle (same views, CPU restatement of cv.calibrateCamera)
+            from tests import _oracle as orc
+            t1 = time.perf_counter()
+            o_rms = orc.calibrate(calib_inputs[0], calib_inputs[1], (1920, 1080), rational=True)[0]
+            out["check"]["calib_rms_vs_oracle"] = abs(calib["rms_px"] - o_rms)
+            out["check"]["calib_oracle_seconds"] = time.perf_counter() - t1
+        if not args.no_extra and world == 1:
+            # secondary configurations, driver-timed with the rest of this run (bench_extra.py holds the legs)
+            import contextlib
+            import bench_extra
+            del frames, d_ids, d_cor, d_cnt, d_rv, d_tv, d_ok
+            torch.cuda.empty_cache()
+            with contextlib.redirect_stdout(sys.stderr):  # the mirror prints what the reference prints
+                out["config2_4k"] = bench_extra.leg_4k(torch, dev, 256, 3, oracle_frames=0 if args.no_cpu else 8)
+                out["photo_scene"] = bench_extra.leg_photo(torch, dev, 4096, 3, oracle_frames=0 if args.no_cpu else 16)
+                out["config5_8cams"] = {"1920x1080": bench_extra.leg_8cams(dev, 1080, 1920, "Logitec_robot", 10, 100),
+                                        "1280x720": bench_extra.leg_8cams(dev, 720, 1280, "Logitec_A", 0, 100)}
+            for k in ("config2_4k", "photo_scene"):
+                out[k].pop("lists_used_and_capacity", None)
         print(json.dumps(out))
     if world > 1:
         dist_mod.barrier()

@@ -24,6 +24,198 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
+def leg_4k(torch, dev, n=256, steps=3, oracle_frames=0, pool=4):
+    """configs[2] on one GPU: detect + PnP on n resident 3840x2160 frames with 40 markers each (pool rendered poses x
+    per-frame noise).  oracle_frames > 0: the first frames' results are compared with the CPU oracle (ids and order
+    exact, corners <= 1e-3 px)."""
+    from cameracalibration_amd import _hip, synth
+    H, W = 2160, 3840
+    K4 = np.array([[2800.0, 0, 1920.0], [0, 2800.0, 1080.0], [0, 0, 1.0]])
+    rendered = [synth.grid_frame(i, K4, device=dev, ss=2, noise_sigma=0.0) for i in range(pool)]
+    clean = torch.stack([r[0][:, :, 0].to(torch.float32) for r in rendered])
+    frames = torch.empty((n, H, W, 3), dtype=torch.uint8, device=dev)
+    g = torch.Generator(device=dev).manual_seed(7)
+    for b0 in range(0, n, 16):
+        nb = min(16, n - b0)
+        idx = torch.arange(b0, b0 + nb, device=dev) % pool
+        noise = torch.randn((nb, H, W, 3), generator=g, device=dev, dtype=torch.float32) * 4.0
+        frames[b0:b0 + nb] = (clean[idx][..., None] + noise).round_().clamp_(0, 255).to(torch.uint8)
+    MM = 64
+    d_ids = torch.full((n, MM), -1, dtype=torch.int32, device=dev)
+    d_cor = torch.zeros((n, MM, 4, 2), dtype=torch.float32, device=dev)
+    d_cnt = torch.zeros((n,), dtype=torch.int32, device=dev)
+    d_rv = torch.zeros((n, 3), dtype=torch.float64, device=dev)
+    d_tv = torch.zeros((n, 3), dtype=torch.float64, device=dev)
+    d_ok = torch.zeros((n,), dtype=torch.uint8, device=dev)
+    ctx = _hip.Context(H, W, max_batch=n, device=dev.index or 0)
+    # anchors: the first four markers of every pose's sheet share ids but not places; the pose leg uses pose 0's
+    sheet0 = rendered[0][1]
+    anchors = [int(m[0]) for m in sheet0[:4]]
+    anchor_obj = np.array([[[x, y, 0], [x + sz, y, 0], [x + sz, y - sz, 0], [x, y - sz, 0]] for (_, x, y, sz) in sheet0[:4]],
+                          np.float32)
+
+    def step4k():
+        ctx.detect_pnp_resident(frames.data_ptr(), n, H, W, 3, anchors, anchor_obj, K4, np.zeros(5), MM,
+                                d_ids.data_ptr(), d_cor.data_ptr(), d_cnt.data_ptr(), d_rv.data_ptr(),
+                                d_tv.data_ptr(), d_ok.data_ptr())
+
+    try:
+        step4k()
+        torch.cuda.synchronize()
+        # size-independent check: every frame shows its sheet's 40 markers and nothing else
+        cnt = d_cnt.cpu().numpy()
+        ids = d_ids.cpu().numpy()
+        want = [sorted(int(m[0]) for m in r[1]) for r in rendered]
+        frames_right = sum(int(cnt[i]) == 40 and sorted(ids[i, :40].tolist()) == want[i % pool] for i in range(n))
+        lists = ctx.debug_lists()
+        ctx.enable_timers(True)
+        ctx.reset_timers()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step4k()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        tm = ctx.timers()
+        ctx.enable_timers(False)
+        res = {
+            "frames": n, "frames_per_s": n / dt, "ms_per_frame": dt / n * 1e3, "ms_per_step": dt * 1e3,
+            "mean_markers_per_frame": float(cnt.mean()),
+            "frames_with_exactly_their_40_markers": frames_right,
+            "hbm_frac_k1k3_11B_per_px": n / dt * H * W * 11.0 / 8e12,
+            "stage_ms_per_step": {k: round(v[0] / steps, 3) for k, v in tm.items()},
+            "lists_used_and_capacity": lists,
+            "note": "configs[2] on one GPU: detect + PnP on 4 sheet markers, resident input, %d rendered poses x per-frame "
+                    "noise (sigma 4)" % pool}
+        if oracle_frames > 0:
+            from concurrent.futures import ThreadPoolExecutor
+            from tests import _oracle as orc
+            k = min(oracle_frames, n)
+            host = frames[:k].cpu().numpy()
+            cor = d_cor[:k].cpu().numpy()
+            with ThreadPoolExecutor(min(k, 16)) as ex:
+                ores = list(ex.map(orc.detect, list(host)))
+            equal, worst = 0, 0.0
+            for i, (oi, oc, _) in enumerate(ores):
+                m = int(cnt[i])
+                if m == len(oi) and ids[i, :m].tolist() == oi.tolist():
+                    e = float(np.abs(cor[i, :m] - oc).max()) if m else 0.0
+                    worst = max(worst, e)
+                    equal += e <= 1e-3
+            res["oracle_frames_compared"] = k
+            res["oracle_frames_equal"] = int(equal)
+            res["max_corner_err_px"] = worst
+    except Exception as e:  # keep the other measurements
+        res = {"error": "%s: %s" % (type(e).__name__, e)}
+    ctx.close()
+    del frames, clean
+    torch.cuda.empty_cache()
+    return res
+
+
+def leg_photo(torch, dev, n=4096, steps=3, oracle_frames=0):
+    """Scene dependence: the reference's own photo pic_2.png (1280x720, textured desk scene, 6 markers) + noise sigma 1
+    per frame as a resident batch, detect + PnP."""
+    from cameracalibration_amd import _hip
+    from tests import _data
+    try:
+        photos = [_data.load_bgr("pic_2.png")]
+        h, w = photos[0].shape[:2]
+        base = torch.stack([torch.from_numpy(np.ascontiguousarray(p)).to(dev) for p in photos])
+        g = torch.Generator(device=dev).manual_seed(11)
+        frames = torch.empty((n, h, w, 3), dtype=torch.uint8, device=dev)
+        for b0 in range(0, n, 64):
+            nb = min(64, n - b0)
+            idx = torch.arange(b0, b0 + nb, device=dev) % len(photos)
+            noise = torch.randn((nb, h, w, 3), generator=g, device=dev, dtype=torch.float32) * 1.0
+            frames[b0:b0 + nb] = (base[idx].to(torch.float32) + noise).round_().clamp_(0, 255).to(torch.uint8)
+        Kp, dp = _data.calibration("Logitec_A_1280-720_0.npz")
+        MM = 16
+        d_ids = torch.full((n, MM), -1, dtype=torch.int32, device=dev)
+        d_cor = torch.zeros((n, MM, 4, 2), dtype=torch.float32, device=dev)
+        d_cnt = torch.zeros((n,), dtype=torch.int32, device=dev)
+        d_rv = torch.zeros((n, 3), dtype=torch.float64, device=dev)
+        d_tv = torch.zeros((n, 3), dtype=torch.float64, device=dev)
+        d_ok = torch.zeros((n,), dtype=torch.uint8, device=dev)
+        ctx = _hip.Context(h, w, max_batch=n, device=dev.index or 0)
+        anchors = [10, 11, 14, 15]
+        anchor_obj = _data.v1_anchor_points(anchors)
+
+        def step_photo():
+            ctx.detect_pnp_resident(frames.data_ptr(), n, h, w, 3, anchors, anchor_obj, Kp, dp, MM, d_ids.data_ptr(),
+                                    d_cor.data_ptr(), d_cnt.data_ptr(), d_rv.data_ptr(), d_tv.data_ptr(), d_ok.data_ptr())
+
+        step_photo()
+        torch.cuda.synchronize()
+        lists = ctx.debug_lists()
+        ctx.enable_timers(True)
+        ctx.reset_timers()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step_photo()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        tm = ctx.timers()
+        px_rate = n / dt * h * w
+        res = {
+            "frames": n, "frames_per_s": n / dt, "ms_per_step": dt * 1e3, "pixels_per_s": px_rate,
+            "as_1080p_frames_per_s_by_pixels": px_rate / (1920 * 1080),
+            "hbm_frac_k1k3_11B_per_px": px_rate * 11.0 / 8e12,
+            "frames_with_pose": int(d_ok.to(torch.int64).sum().item()), "mean_markers_per_frame": float(d_cnt.to(torch.float64).mean().item()),
+            "stage_ms_per_step": {k: round(v[0] / steps, 3) for k, v in tm.items()}, "lists_used_and_capacity": lists,
+            "note": "the reference's pic_2.png (desk scene, 6 markers) + noise sigma 1 per frame; "
+                    "detect + PnP, resident input: how much the bench number depends on its flat synthetic background"}
+        if oracle_frames > 0:
+            from concurrent.futures import ThreadPoolExecutor
+            from tests import _oracle as orc
+            k = min(oracle_frames, n)
+            host = frames[:k].cpu().numpy()
+            ids, cor, cnt = d_ids[:k].cpu().numpy(), d_cor[:k].cpu().numpy(), d_cnt[:k].cpu().numpy()
+            with ThreadPoolExecutor(min(k, 16)) as ex:
+                ores = list(ex.map(orc.detect, list(host)))
+            equal = 0
+            for i, (oi, oc, _) in enumerate(ores):
+                m = int(cnt[i])
+                equal += m == len(oi) and ids[i, :m].tolist() == oi.tolist() and (m == 0 or float(np.abs(cor[i, :m] - oc).max()) <= 1e-3)
+            res["oracle_frames_compared"] = k
+            res["oracle_frames_equal"] = int(equal)
+        ctx.close()
+        del frames
+        torch.cuda.empty_cache()
+        return res
+    except Exception as e:
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+
+
+def leg_8cams(dev, h, w, camname, focus, sets=200):
+    """configs[4]: wall latency of processArucoFromMultipleCameras for 8 cameras looking at one scene (host frames in,
+    mirror API, fused marker corners out)."""
+    from cameracalibration_amd import synth
+    from cameracalibration_amd.camera_sync import aruco as A
+    from cameracalibration_amd.camera_sync.camera import Camera
+    try:
+        cams = [Camera(camname, -1, focus=focus, resolution=(w, h)) for _ in range(8)]
+        Kc = np.asarray(cams[0].mtx, dtype=np.float64)
+        views = [synth.v1_frame(100 + i, Kc, H=h, W=w, device=dev, ss=2)[0].cpu().numpy() for i in range(8)]
+        sheet = A.getArucosFromPaper(1)
+        fixed = [sheet[i] for i in (10, 11, 14, 15)]
+        moving = {12: sheet[12], 13: sheet[13]}
+        lat = []
+        A.processArucoFromMultipleCameras(fixed, moving, cams, views)
+        for _ in range(sets):
+            t0 = time.perf_counter()
+            A.processArucoFromMultipleCameras(fixed, moving, cams, views)
+            lat.append((time.perf_counter() - t0) * 1e3)
+        lat = np.array(lat)
+        located = sum(hasattr(c, "world2cam") for c in cams)
+        return {"sets": sets, "p50_ms": float(np.percentile(lat, 50)), "p99_ms": float(np.percentile(lat, 99)),
+                "cameras_located": int(located),
+                "note": "configs[4]: 8 host frames (pageable memory) per set through the mirror API: one detection + "
+                        "anchor-PnP launch sequence for all cameras, one IPPE + fusion call for all moving markers; "
+                        "includes the host-to-device copies"}
+    except Exception as e:
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames4k", type=int, default=256, help="frames of the 4K configuration (0 = skip)")
@@ -49,127 +241,14 @@ def main():
     _quiet.__enter__()
 
     if args.frames4k > 0:
-        # ---- configs[2], one GPU: 4K, 40 markers per frame ----
-        H, W = 2160, 3840
-        K4 = np.array([[2800.0, 0, 1920.0], [0, 2800.0, 1080.0], [0, 0, 1.0]])
-        pool = 4
-        rendered = [synth.grid_frame(i, K4, device=dev, ss=2, noise_sigma=0.0) for i in range(pool)]
-        clean = torch.stack([r[0][:, :, 0].to(torch.float32) for r in rendered])
-        n = args.frames4k
-        frames = torch.empty((n, H, W, 3), dtype=torch.uint8, device=dev)
-        g = torch.Generator(device=dev).manual_seed(7)
-        for b0 in range(0, n, 16):
-            nb = min(16, n - b0)
-            idx = torch.arange(b0, b0 + nb, device=dev) % pool
-            noise = torch.randn((nb, H, W, 3), generator=g, device=dev, dtype=torch.float32) * 4.0
-            frames[b0:b0 + nb] = (clean[idx][..., None] + noise).round_().clamp_(0, 255).to(torch.uint8)
-        MM = 64
-        d_ids = torch.full((n, MM), -1, dtype=torch.int32, device=dev)
-        d_cor = torch.zeros((n, MM, 4, 2), dtype=torch.float32, device=dev)
-        d_cnt = torch.zeros((n,), dtype=torch.int32, device=dev)
-        d_rv = torch.zeros((n, 3), dtype=torch.float64, device=dev)
-        d_tv = torch.zeros((n, 3), dtype=torch.float64, device=dev)
-        d_ok = torch.zeros((n,), dtype=torch.uint8, device=dev)
-        ctx = _hip.Context(H, W, max_batch=n, device=0)
-        # anchors: the first four markers of every pose's sheet share ids but not places; the pose leg uses pose 0's
-        sheet0 = rendered[0][1]
-        anchors = [int(m[0]) for m in sheet0[:4]]
-        anchor_obj = np.array([[[x, y, 0], [x + sz, y, 0], [x + sz, y - sz, 0], [x, y - sz, 0]] for (_, x, y, sz) in sheet0[:4]],
-                              np.float32)
-
-        def step4k():
-            ctx.detect_pnp_resident(frames.data_ptr(), n, H, W, 3, anchors, anchor_obj, K4, np.zeros(5), MM,
-                                    d_ids.data_ptr(), d_cor.data_ptr(), d_cnt.data_ptr(), d_rv.data_ptr(),
-                                    d_tv.data_ptr(), d_ok.data_ptr())
-
-        try:
-            step4k()
-            torch.cuda.synchronize()
-            # size-independent check: every frame shows its sheet's 40 markers and nothing else
-            cnt = d_cnt.cpu().numpy()
-            ids = d_ids.cpu().numpy()
-            want = [sorted(int(m[0]) for m in r[1]) for r in rendered]
-            frames_right = sum(int(cnt[i]) == 40 and sorted(ids[i, :40].tolist()) == want[i % pool] for i in range(n))
-            lists = ctx.debug_lists()
-            ctx.enable_timers(True)
-            ctx.reset_timers()
-            t0 = time.perf_counter()
-            for _ in range(args.steps4k):
-                step4k()
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t0) / args.steps4k
-            tm = ctx.timers()
-            ctx.enable_timers(False)
-            out["config2_4k_one_gpu"] = {
-                "frames": n, "frames_per_s": n / dt, "ms_per_frame": dt / n * 1e3,
-                "mean_markers_per_frame": float(cnt.mean()),
-                "frames_with_exactly_their_40_markers": frames_right,
-                "hbm_frac_k1k3_11B_per_px": n / dt * H * W * 11.0 / 8e12,
-                "stage_ms_per_step": {k: round(v[0] / args.steps4k, 3) for k, v in tm.items()},
-                "lists_used_and_capacity": lists,
-                "note": "detect + PnP on 4 sheet markers, resident input, %d rendered poses x per-frame noise (sigma 4)" % pool}
-        except Exception as e:  # keep the other measurements
-            out["config2_4k_one_gpu"] = {"error": str(e)}
-        del frames, clean, ctx
-        torch.cuda.empty_cache()
+        out["config2_4k_one_gpu"] = leg_4k(torch, dev, args.frames4k, args.steps4k)
 
     if args.only4k:
         _quiet.__exit__(None, None, None)
         print(json.dumps(out))
         return
 
-    # ---- scene dependence: the reference's own photos (1280x720, textured background) as a resident batch ----
-    try:
-        photos = [_data.load_bgr("pic_2.png")]
-        h, w = photos[0].shape[:2]
-        n = args.photo_frames
-        base = torch.stack([torch.from_numpy(np.ascontiguousarray(p)).to(dev) for p in photos])
-        g = torch.Generator(device=dev).manual_seed(11)
-        frames = torch.empty((n, h, w, 3), dtype=torch.uint8, device=dev)
-        for b0 in range(0, n, 64):
-            nb = min(64, n - b0)
-            idx = torch.arange(b0, b0 + nb, device=dev) % len(photos)
-            noise = torch.randn((nb, h, w, 3), generator=g, device=dev, dtype=torch.float32) * 1.0
-            frames[b0:b0 + nb] = (base[idx].to(torch.float32) + noise).round_().clamp_(0, 255).to(torch.uint8)
-        Kp, dp = _data.calibration("Logitec_A_1280-720_0.npz")
-        MM = 16
-        d_ids = torch.full((n, MM), -1, dtype=torch.int32, device=dev)
-        d_cor = torch.zeros((n, MM, 4, 2), dtype=torch.float32, device=dev)
-        d_cnt = torch.zeros((n,), dtype=torch.int32, device=dev)
-        d_rv = torch.zeros((n, 3), dtype=torch.float64, device=dev)
-        d_tv = torch.zeros((n, 3), dtype=torch.float64, device=dev)
-        d_ok = torch.zeros((n,), dtype=torch.uint8, device=dev)
-        ctx = _hip.Context(h, w, max_batch=n, device=0)
-        anchors = [10, 11, 14, 15]
-        anchor_obj = _data.v1_anchor_points(anchors)
-
-        def step_photo():
-            ctx.detect_pnp_resident(frames.data_ptr(), n, h, w, 3, anchors, anchor_obj, Kp, dp, MM, d_ids.data_ptr(),
-                                    d_cor.data_ptr(), d_cnt.data_ptr(), d_rv.data_ptr(), d_tv.data_ptr(), d_ok.data_ptr())
-
-        step_photo()
-        torch.cuda.synchronize()
-        lists = ctx.debug_lists()
-        ctx.enable_timers(True)
-        ctx.reset_timers()
-        t0 = time.perf_counter()
-        for _ in range(3):
-            step_photo()
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / 3
-        tm = ctx.timers()
-        px_rate = n / dt * h * w
-        out["photos_1280x720"] = {
-            "frames": n, "frames_per_s": n / dt, "pixels_per_s": px_rate,
-            "as_1080p_frames_per_s_by_pixels": px_rate / (1920 * 1080),
-            "frames_with_pose": int(d_ok.to(torch.int64).sum().item()), "mean_markers_per_frame": float(d_cnt.to(torch.float64).mean().item()),
-            "stage_ms_per_step": {k: round(v[0] / 3, 3) for k, v in tm.items()}, "lists_used_and_capacity": lists,
-            "note": "the reference's pic_2.png (desk scene, 6 markers) + noise sigma 1 per frame; "
-                    "detect + PnP, resident input: how much the bench number depends on its flat synthetic background"}
-        del frames, ctx
-        torch.cuda.empty_cache()
-    except Exception as e:
-        out["photos_1280x720"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    out["photos_1280x720"] = leg_photo(torch, dev, args.photo_frames)
 
     # ---- host frames in: the PCIe-inclusive rate of detect + PnP, pageable against page-locked frame buffers ----
     try:
@@ -231,27 +310,7 @@ def main():
     # ---- config 5: 8 cameras, one scene, processArucoFromMultipleCameras (host frames, mirror API) ----
     K, dist = _data.calibration("Logitec_robot_1920-1080_10.npz")
     for (h, w, camname, focus) in ((720, 1280, "Logitec_A", 0), (1080, 1920, "Logitec_robot", 10)):
-        cams = [Camera(camname, -1, focus=focus, resolution=(w, h)) for _ in range(8)]
-        Kc = np.asarray(cams[0].mtx, dtype=np.float64)
-        views = [synth.v1_frame(100 + i, Kc, H=h, W=w, device=dev, ss=2)[0].cpu().numpy() for i in range(8)]
-        sheet = A.getArucosFromPaper(1)
-        fixed = [sheet[i] for i in (10, 11, 14, 15)]
-        moving = {12: sheet[12], 13: sheet[13]}
-        lat = []
-        try:
-            A.processArucoFromMultipleCameras(fixed, moving, cams, views)
-            for _ in range(args.sets):
-                t0 = time.perf_counter()
-                A.processArucoFromMultipleCameras(fixed, moving, cams, views)
-                lat.append((time.perf_counter() - t0) * 1e3)
-            lat = np.array(lat)
-            out["config5_8cams_%dx%d" % (w, h)] = {
-                "sets": args.sets, "p50_ms": float(np.percentile(lat, 50)), "p99_ms": float(np.percentile(lat, 99)),
-                "note": "8 host frames (pageable memory) per set through the mirror API: one detection + anchor-PnP "
-                        "launch sequence for all cameras, one IPPE call for all moving markers, fusion on the host; "
-                        "includes the host-to-device copies"}
-        except Exception as e:
-            out["config5_8cams_%dx%d" % (w, h)] = {"error": "%s: %s" % (type(e).__name__, e)}
+        out["config5_8cams_%dx%d" % (w, h)] = leg_8cams(dev, h, w, camname, focus, args.sets)
 
     # ---- single frame: detectAruco on one host frame ----
     try:
