@@ -355,7 +355,7 @@ def main():
             dist_mod.all_reduce(tcal, op=dist_mod.ReduceOp.MAX)
             calib = {"views": args.calib_views, "views_per_rank": span[1] - span[0], "iters": iters,
                      "iters_per_s": iters / float(tcal[0].item()), "rms_px": rms,
-                     "allreduce_calls": stats.get("calls"), "allreduce_share": float(tcal[1].item()) / float(tcal[0].item()),
+                     "allreduce_calls": stats.get("calls"), "allreduce_host_issue_share": float(tcal[1].item()) / float(tcal[0].item()),
                      "includes": "context + init (homographies + per-view PnP) + LM, records summed by RCCL"}
     except Exception as e:  # secondary; never hide the main line
         calib = {"error": "%s: %s" % (type(e).__name__, e)}

@@ -3,14 +3,16 @@ camera_sync/camera.py:61-63) with the views sharded over ranks.
 
 One process per GPU.  Rank g holds the contiguous share views[lo:hi] (shard_range) and, per LM iteration,
 eliminates its views' extrinsic blocks on the GPU (Schur complement) into the record
-[S (NI x NI) | rhs (NI) | err] — at most 157 doubles — which is summed over ranks with one all-reduce.
-Every rank then solves the same NI x NI system redundantly and back-substitutes its own views, so no
-parameters are ever broadcast.  A second, 3-double all-reduce carries the error of the trial step and the
-parameter-change sums.  The control flow is CvLevMarq::updateAlt's.
+[S (NI x NI) | rhs (NI) | err | parameter-change sums] — at most 159 doubles — which is summed over ranks with ONE
+all-reduce per trial step (the kernel that evaluates a trial step also forms the trial parameters' record, so the
+trial's error and the next iteration's normal equations travel in the same message).  Every rank then solves the same
+NI x NI system redundantly and back-substitutes its own views, so no parameters are ever broadcast.  The control flow
+is CvLevMarq::updateAlt's.
 
 `calibrate_distributed` runs the loop inside the library (camsync_calibrate_dist: device-resident, one host
 read-back per trial step) and supplies the collective as a callback: torch.distributed.all_reduce — RCCL when the
-process group's backend is "nccl" — on a slice of the torch tensor the library keeps its records in.
+process group's backend is "nccl" — on a slice of the torch tensor the library keeps its records in, issued on the
+library's own stream (no host synchronisation around the collective).
 `lm_calibrate` is the same loop on the host over the camsync_calib_* building blocks (any worker object with
 that interface; tests/test_distributed.py runs it over gloo without a GPU).
 """
@@ -139,8 +141,13 @@ def lm_calibrate(worker, image_size, n_views_total, allreduce, max_iter=30):
 
 def make_device_allreduce(work, group=None, stats=None):
     """The camsync_allreduce_fn for torch.distributed: `work` is the float64 device tensor handed to the library
-    as its work buffer; the library asks for slices of it to be summed over the ranks in place.  `stats` (a dict)
-    receives the number of calls and the seconds spent in them."""
+    as its work buffer; the library asks for slices of it to be summed over the ranks in place, on its own stream.
+
+    The collective is issued in stream order: the library's HIP stream is wrapped as a torch ExternalStream and made
+    current for the call, so RCCL's kernel waits (on the device) for the kernel that produced the record and the
+    library's next kernel waits for RCCL's -- the host synchronises nowhere in here.  With the gloo backend (CPU
+    tests) the record goes through the host, which waits for that one stream only.
+    `stats` (a dict) receives the number of calls and the host seconds spent issuing them."""
     import time
 
     import torch
@@ -149,6 +156,7 @@ def make_device_allreduce(work, group=None, stats=None):
     base = work.data_ptr()
     dev = work.device
     backend = dist.get_backend(group)
+    streams = {}
 
     def allreduce(d_buf, n, stream):
         t0 = time.perf_counter()
@@ -156,14 +164,17 @@ def make_device_allreduce(work, group=None, stats=None):
         if off < 0 or off + n > work.numel() or (d_buf - base) % 8:
             raise ValueError("all-reduce request outside the work buffer")
         view = work[off:off + n]
-        torch.cuda.synchronize(dev)  # the library's stream is not torch's: everything it enqueued must have landed
-        if backend == "nccl":        # RCCL on the device buffer itself
-            dist.all_reduce(view, op=dist.ReduceOp.SUM, group=group)
-        else:                        # gloo (tests): through the host
-            h = view.cpu()
-            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
-            view.copy_(h)
-        torch.cuda.synchronize(dev)
+        ext = streams.get(stream)
+        if ext is None:
+            ext = streams[stream] = torch.cuda.ExternalStream(stream, device=dev) if stream else torch.cuda.default_stream(dev)
+        with torch.cuda.stream(ext):
+            if backend == "nccl":        # RCCL on the device buffer itself, ordered on the library's stream
+                dist.all_reduce(view, op=dist.ReduceOp.SUM, group=group)
+            else:                        # gloo (tests): through the host
+                h = view.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+                view.copy_(h)
+                ext.synchronize()
         if stats is not None:
             stats["calls"] = stats.get("calls", 0) + 1
             stats["seconds"] = stats.get("seconds", 0.0) + time.perf_counter() - t0

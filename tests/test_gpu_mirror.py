@@ -372,7 +372,9 @@ def test_distributed_calibration_over_rccl_world_1(tmp_path):
     obj, img, _, _ = synth.calib_views(V=V, seed=5, rational=True)
     ctx = _hip.Context(32, 32, 1)
     rms1, K1, d1, rv1, tv1, it1 = ctx.calibrate(obj, img, (1920, 1080), rational=True)
-    assert int(r["iters"]) == it1 and int(r["calls"]) >= 1 + 2 * it1  # focal sums + (record, trial) per iteration
+    # one collective for the focal sums, one for the first record, then ONE per trial step (the trial's error travels
+    # with the record of the trial parameters; a rejected step costs a second one for the re-damped record)
+    assert int(r["iters"]) == it1 and int(r["calls"]) >= 2 + it1, (it1, int(r["calls"]))
     assert float(r["rms"]) == rms1
     assert np.array_equal(r["K"], K1) and np.array_equal(r["d"], d1)
     assert np.array_equal(r["rv"], rv1) and np.array_equal(r["tv"], tv1)
