@@ -468,6 +468,7 @@ int camsync_create(camsync_ctx** out, int device, int max_h, int max_w, int max_
     constexpr size_t kSlackWaves = 16384;
     b.contourCap = (unsigned)std::min<size_t>(B * 4096 + kSlackWaves * 32, 0x7FFFFFFFu);
     HIPCHK(c, dalloc(&b.contours, b.contourCap));
+    HIPCHK(c, dalloc(&b.binIdx, (size_t)b.contourCap * 5));
     b.poolCap = (unsigned)std::min<size_t>(B * std::max<size_t>(262144, px / 8) + kSlackWaves * 8192, 0x7FFFFFFFu);
     HIPCHK(c, dalloc(&b.pool, b.poolCap));
     b.taskCap = (unsigned)std::min<size_t>((size_t)b.contourCap * 2 + b.poolCap / kCkStride + kSlackWaves * 64, 0x7FFFFFFFu);
@@ -540,7 +541,7 @@ void camsync_destroy(camsync_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DetBuffers& b = c->buf;
     void* ptrs[] = {c->d_chessGray, c->d_chessS, c->d_chessR, c->d_chessCand, c->d_chessMax, c->d_chessCount, c->d_spIn, c->d_spOut, c->d_spN,
-                    c->d_umap, c->d_uout, c->d_in, c->d_bin, b.planes, b.gray, b.cand, b.candLong, b.contours, b.pool, b.tasks, b.seeds, b.seg, b.seedTable, b.chain, b.copies, b.resolveLog, b.quads, b.persp, b.idList, b.idCount, b.selState, b.qcount, b.counters, b.markers,
+                    c->d_umap, c->d_uout, c->d_in, c->d_bin, b.planes, b.gray, b.cand, b.candLong, b.contours, b.binIdx, b.pool, b.tasks, b.seeds, b.seg, b.seedTable, b.chain, b.copies, b.resolveLog, b.quads, b.persp, b.idList, b.idCount, b.selState, b.qcount, b.counters, b.markers,
                     b.outIds, b.outCorners, b.rawCorners, b.outCounts, b.outRejected, b.outRejCounts, c->d_dict, c->d_expTab,
                     c->d_obj, c->d_img, c->d_npts, c->d_K, c->d_dist, c->d_rvec, c->d_tvec, c->d_mae, c->d_rmse, c->d_ok,
                     c->d_anchorIds, c->d_anchorObj, c->d_calObj, c->d_calImg, c->cal.intr, c->cal.ext, c->cal.intrTrial,

@@ -164,6 +164,7 @@ struct Counters {
     alignas(128) unsigned int nVirt;     // continuation segments handed out by the segment walkers (ids count down from segCap - 1)
     alignas(128) unsigned int qWalk;     // work-queue heads of the segment walkers (seeds) and of the resolve pass
     alignas(128) unsigned int qResolve;
+    alignas(128) unsigned int nBin[5 * 32];  // contours per length bin of the quad fit, one cache line each: nBin[32 k]
     alignas(128) unsigned int pad;
 };
 
@@ -221,6 +222,7 @@ struct DetBuffers {
     SegRec* seg;         // [segCap] ids: [0, nSeeds) seeds, [nSeeds, nSeeds + nLong) start candidates, continuations from the top down
     unsigned int segCap;
     uint32_t* seedTable;  // seed -> id, one table per bit plane indexed by the seed's place on the grid lines (k_contours.hip)
+    uint32_t* binIdx;    // [5][contourCap] contour indices by length bin (k_quad_bin)
     QuadRec* quads;      // [B,kQuadCap]
     int* qcount;         // [B]
     Counters* counters;
