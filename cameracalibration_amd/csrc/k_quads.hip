@@ -45,6 +45,13 @@ __device__ __forceinline__ int wrap_once(int i, int n) { return (int)min((uint32
 struct IPt { int x, y; };
 __device__ __forceinline__ IPt unpack_pt(uint32_t p) { return IPt{(int)(p & 0xFFFFu), (int)(p >> 16)}; }
 
+// lanes of one wavefront exchange data through LDS in program order: only the compiler has to keep it
+__device__ __forceinline__ void wave_lds_order() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // Douglas-Peucker's clean-up pass on the <= 8 vertices in dst, then the quad tests of _findMarkerContours (4 vertices,
 // convex, minimum side, distance to the image border), the clockwise reorder and the append to the frame's list.
 // Scalar work: one lane per contour runs it.
@@ -254,6 +261,137 @@ __global__ __launch_bounds__(64) void k_quad_fit(const ContourRec* __restrict__ 
 }
 
 
+// The same for contours of up to kFitWave = 2048 points (nearly all that reach this kernel: marker outlines are a
+// few hundred to a thousand points): always in LDS, the farthest point and its position as one key (distance << 11 |
+// 2047 - offset: one wave reduction per round instead of two; a closed chain of 2048 points spans at most 1024 pixels,
+// so cross products and squared lengths stay below 2^21), four points per lane in flight per scan step.
+constexpr int kFitWaveN = 2048, kFitWaveKS = 11;
+__global__ __launch_bounds__(64) void k_quad_wave(const ContourRec* __restrict__ contours, const uint32_t* __restrict__ list,
+                                                  const unsigned int* __restrict__ count, unsigned int contourCap,
+                                                  const uint32_t* __restrict__ pool, unsigned int poolCap, int B,
+                                                  QuadRec* __restrict__ quads, int* __restrict__ qcount,
+                                                  Counters* __restrict__ ctr, DetCfg cfg) {
+    constexpr int KS = kFitWaveKS;
+    constexpr uint32_t KMASK = (1u << KS) - 1u;
+    static_assert(kFitWaveN <= (1 << KS) && (uint64_t)kFitWaveN * kFitWaveN / 2 <= (1ull << (32 - KS)), "key layout");
+    __shared__ int s_stack[32][2];
+    __shared__ IPt s_dst[16];
+    __shared__ uint32_t s_pts[kFitWaveN + 256];  // (+ what a scan's last step may read past the end: read, never used)
+    const int lane = threadIdx.x;
+    const unsigned int nC = min(*count, contourCap);
+    const auto wave_max = [](uint32_t v) { return wave_allreduce(v, [](uint32_t x, uint32_t y) { return x > y ? x : y; }); };
+    for (unsigned int li = blockIdx.x; li < nC; li += gridDim.x) {
+        const ContourRec rec = contours[min(list[li], contourCap - 1u)];
+        const int n = (int)rec.len;
+        if (n <= 0 || n > kFitWaveN || n > cfg.maxPerim || rec.frame >= (unsigned int)B || rec.off >= poolCap || rec.len > poolCap - rec.off)
+            continue;  // (k_quad_bin lists none of these)
+        const uint32_t* __restrict__ G = pool + rec.off;
+        wave_lds_order();
+        // all of the contour's loads in flight at once, eight per lane and step (a loop of load, wait, store pays one
+        // memory latency per 64 points)
+        for (int i0 = 0; i0 < n; i0 += 512) {
+            uint32_t v[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) v[q] = (i0 + 64 * q + lane < n) ? G[i0 + 64 * q + lane] : 0u;
+#pragma unroll
+            for (int q = 0; q < 8; q++)
+                if (i0 + 64 * q + lane < n) s_pts[i0 + 64 * q + lane] = v[q];
+        }
+        wave_lds_order();
+        double eps = (double)n * cfg.accuracyRate;
+        eps *= eps;
+
+        // 1. approximately the two farthest points (3 rounds)
+        int pos = 0, rs = 0;
+        bool le_eps = false;
+        for (int it = 0; it < 3; it++) {
+            pos += rs;
+            if (pos >= n) pos -= n;
+            const uint32_t sp = s_pts[pos];
+            uint32_t best = 0;
+            for (int j = 1 + lane; j < n; j += 256) {  // (uniform trip count: j - lane is)
+                const uint32_t p0 = s_pts[wrap_once(pos + j, n)], p1 = s_pts[wrap_once(pos + j + 64, n)];
+                const uint32_t p2 = s_pts[wrap_once(pos + j + 128, n)], p3 = s_pts[wrap_once(pos + j + 192, n)];
+                const uint32_t k0 = j < n ? (sq_norm(pt_diff(p0, sp)) << KS) | (KMASK - (uint32_t)j) : 0u;
+                const uint32_t k1 = j + 64 < n ? (sq_norm(pt_diff(p1, sp)) << KS) | (KMASK - (uint32_t)(j + 64)) : 0u;
+                const uint32_t k2 = j + 128 < n ? (sq_norm(pt_diff(p2, sp)) << KS) | (KMASK - (uint32_t)(j + 128)) : 0u;
+                const uint32_t k3 = j + 192 < n ? (sq_norm(pt_diff(p3, sp)) << KS) | (KMASK - (uint32_t)(j + 192)) : 0u;
+                best = max(max(best, k0), max(k1, max(k2, k3)));
+            }
+            best = wave_max(best);
+            const uint32_t maxd = best >> KS;
+            if (maxd > 0) rs = (int)(KMASK - (best & KMASK));
+            le_eps = (double)maxd <= eps;
+        }
+        if (le_eps) continue;  // (one vertex: no quad)
+
+        int top = 2, cnt = 0;
+        bool reject = false;
+        {
+            const int a = pos;
+            int b = rs + a;
+            if (b >= n) b -= n;
+            if (lane == 0) {
+                s_stack[0][0] = b; s_stack[0][1] = a;  // right slice
+                s_stack[1][0] = a; s_stack[1][1] = b;  // slice
+            }
+        }
+        wave_lds_order();
+
+        // 2. recursive split
+        while (top > 0) {
+            top--;
+            const int a = s_stack[top][0], b = s_stack[top][1];
+            const uint32_t spw = s_pts[a];
+            const IPt sp = unpack_pt(spw), ep = unpack_pt(s_pts[b]);
+            int first = a + 1;
+            if (first >= n) first = 0;
+            bool le = true;
+            int split = 0;
+            if (first != b) {
+                int L = b - a - 1;
+                if (L < 0) L += n;
+                const int dx = ep.x - sp.x, dy = ep.y - sp.y;
+                const pt16 coef = cross_coef(dx, dy);
+                uint32_t best = 0;
+                for (int t = lane; t < L; t += 256) {
+                    const uint32_t p0 = s_pts[wrap_once(first + t, n)], p1 = s_pts[wrap_once(first + t + 64, n)];
+                    const uint32_t p2 = s_pts[wrap_once(first + t + 128, n)], p3 = s_pts[wrap_once(first + t + 192, n)];
+                    const uint32_t k0 = t < L ? (abs_cross(pt_diff(p0, spw), coef) << KS) | (KMASK - (uint32_t)t) : 0u;
+                    const uint32_t k1 = t + 64 < L ? (abs_cross(pt_diff(p1, spw), coef) << KS) | (KMASK - (uint32_t)(t + 64)) : 0u;
+                    const uint32_t k2 = t + 128 < L ? (abs_cross(pt_diff(p2, spw), coef) << KS) | (KMASK - (uint32_t)(t + 128)) : 0u;
+                    const uint32_t k3 = t + 192 < L ? (abs_cross(pt_diff(p3, spw), coef) << KS) | (KMASK - (uint32_t)(t + 192)) : 0u;
+                    best = max(max(best, k0), max(k1, max(k2, k3)));
+                }
+                best = wave_max(best);
+                const double maxd = (double)(best >> KS);
+                if ((best >> KS) > 0) split = wrap_once(first + (int)(KMASK - (best & KMASK)), n);
+                le = maxd * maxd <= eps * (double)(__mul24(dx, dx) + __mul24(dy, dy));
+            }
+            wave_lds_order();  // (the stack entry has been read)
+            if (le) {
+                if (lane == 0) s_dst[cnt] = sp;
+                cnt++;
+            } else {
+                if (lane == 0) {
+                    s_stack[top][0] = split; s_stack[top][1] = b;
+                    s_stack[top + 1][0] = a; s_stack[top + 1][1] = split;
+                }
+                top += 2;
+            }
+            // every slice still on the stack ends in at least one more vertex: with more than 8 in sight the polygon is
+            // lost (approxPolyDP's clean-up pass only removes vertices, and the quad test wants 4 of at most 8)
+            if (cnt + top > 8) { reject = true; break; }
+            wave_lds_order();
+        }
+        if (reject || cnt < 4) continue;
+        wave_lds_order();
+        // 3. clean-up pass on <= 8 vertices, then the quad tests; scalar work on lane 0
+        if (lane == 0) finish_polygon(s_dst, cnt, eps, n, rec, quads, qcount, ctr, cfg);
+    }
+}
+
+
 // ---- short contours: four per wavefront -----------------------------------------------------------------
 // A textured scene has hundreds of contours per frame that are a hundred-odd points long (the reference's desk photo:
 // 500 per frame, 165 points on average).  With a wavefront per contour such a contour is two or three points per lane,
@@ -290,12 +428,6 @@ __device__ __forceinline__ Far row_farthest(uint32_t d, uint32_t j) {
     const uint32_t m = row_allreduce(d, [](uint32_t a, uint32_t b) { return a > b ? a : b; });
     const uint32_t jj = row_allreduce(d == m ? j : 0xFFFFFFFFu, [](uint32_t a, uint32_t b) { return a < b ? a : b; });
     return Far{m, jj};
-}
-// lanes of one wavefront exchange data through LDS in program order: only the compiler has to keep it
-__device__ __forceinline__ void wave_lds_order() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // Douglas-Peucker level by level instead of slice by slice.  The recursion splits every slice independently of the
@@ -569,9 +701,9 @@ void launch_quad_fit(const DetCfg& c, const DetBuffers& b, int B, hipStream_t st
                        b.pool, b.poolCap, B, b.quads, b.qcount, b.counters, c);
     hipLaunchKernelGGL((k_quad_rows<16, kFitShort, 9>), dim3(blocks), dim3(64), 0, st, b.contours, b.binIdx + 2 * cap, &b.counters->nBin[64],
                        b.contourCap, b.pool, b.poolCap, B, b.quads, b.qcount, b.counters, c);
-    // (a whole wavefront per contour going level by level, k_quad_rows<64, 2048, 11>, was slower than k_quad_fit's
+    // (a whole wavefront per contour going level by level, k_quad_rows<64, 2048, 11>, was slower than k_quad_wave's
     // depth-first rounds on the same contours: 2.1 against 1.2 ms on the photo scene, 1.7 against 1.2 ms on the bench scene)
-    hipLaunchKernelGGL(k_quad_fit, dim3(blocks), dim3(64), 0, st, b.contours, b.binIdx + 3 * cap, &b.counters->nBin[96], b.contourCap,
+    hipLaunchKernelGGL(k_quad_wave, dim3(blocks), dim3(64), 0, st, b.contours, b.binIdx + 3 * cap, &b.counters->nBin[96], b.contourCap,
                        b.pool, b.poolCap, B, b.quads, b.qcount, b.counters, c);
     hipLaunchKernelGGL(k_quad_fit, dim3(blocks), dim3(64), 0, st, b.contours, b.binIdx + 4 * cap, &b.counters->nBin[128], b.contourCap,
                        b.pool, b.poolCap, B, b.quads, b.qcount, b.counters, c);
