@@ -29,7 +29,7 @@
 //       states (pixel, direction to the predecessor) under a bijective successor
 //       map, so it can start anywhere: k_contour_starts also lists *seeds*,
 //       cracks on a 64-pixel grid that are recognisable from the 3x3
-//       neighbourhood, and k_seg_walk follows every border from each seed (and
+//       neighbourhood, and k_seg_walk2 follows every border from each seed (and
 //       from each candidate) to the next seed inside a private LDS window,
 //       recording chain codes: the longest dependent chain is one segment, not
 //       one border.  k_seg_link turns "ends at the seed at this position" into
@@ -411,7 +411,7 @@ __device__ __forceinline__ uint32_t pack_state(int x, int y, int sdir) { return 
 // and OpenCV's contour is the list of pixels along the cycle from the start state.
 //
 // Because T is a bijection a border can be entered anywhere: the long borders are followed in segments from seed to
-// seed (k_seg_walk below), which makes the longest dependent chain one segment instead of one border; the segments'
+// seed (k_seg_walk2 below), which makes the longest dependent chain one segment instead of one border; the segments'
 // records are linked and the start rule applied afterwards (k_seg_link, k_resolve).
 //
 // The followers are persistent; every lane follows its border inside a private LDS window of its bit plane: 2 x 2
@@ -874,6 +874,7 @@ __device__ __forceinline__ bool seed_supported(uint32_t m, int dir) {
                      : ((m & 0x0Eu) && (m & 0xE0u));  // west / east crack: something above and below
 }
 
+// ---- the segment walkers --------------------------------------------------------------------------------------
 // One lane per work item: items [0, nSeeds) are seeds, [nSeeds, nSeeds + nLong) the start candidates the short pass
 // left undecided.  A lane follows its border forwards (successor map T, inside its private LDS window) and records
 // the direction of every step, until its sweep passes the crack of a seed: the segment ends there and the record
@@ -883,17 +884,143 @@ __device__ __forceinline__ bool seed_supported(uint32_t m, int dir) {
 // and gives up as soon as it meets a crack with a smaller raster key (it is not the canonical start) or exceeds the
 // length bound.  Lanes hold their next work item in registers, so that taking it up does not wait for memory.
 // CANDS = false: the work items are the seeds; true: the long start candidates, whose step also keeps the start rule's
-// books (smaller key met: not the canonical start; closure without a seed; length bound).  Seeds are five items in six and
-// their step is a fifth shorter, so a wave works on one kind at a time (k_seg_walk).  `wave` of `nWaves` take a first
-// batch of items each without asking the shared counter (wave >= nWaves: this wave only helps to drain the queue).
+// books (smaller key met: not the canonical start; closure without a seed; length bound).  Seeds are five items in six
+// and their step is shorter, so a wave works on one kind at a time.  `wave` of `nWaves` take a first batch of items
+// each without asking the shared counter (wave >= nWaves: this wave only helps to drain the queue).
+//
+// Everything that touches global memory or is rare -- writing a finished segment's record, taking up the next work
+// item, moving a lane's window -- happens in a service phase every kWalk2Steps steps, for all lanes that need it at
+// once (with 64 independent lanes whatever one lane needs once in its life the wavefront executes nearly every time:
+// a service phase costs about as many instructions as five steps).  Between two phases the steps are written out, LDS
+// and registers only; a lane that runs out of window or finishes its segment waits for the next phase.
+//
+// A step is a table lookup at heart: the 3x3 neighbourhood and the direction to the predecessor decide the next pixel,
+// whether the sweep passes the pixel's east crack, and -- for each of the four cracks a seed can sit on -- whether the
+// sweep passes it with the border going on on both sides.  The table (4096 entries of 16 bits, built per workgroup at
+// the start of the kernel) lives in LDS:
+//   index  = row above (x-1, x, x+1) | row << 3 | row below << 6 | direction to the predecessor << 9
+//   bits 0-2  q, the direction of the step            bit 3  the sweep passes the east crack
+//   bits 4-11 a two-bit field per crack (west, east, north, south: the order rows y = 0 / 32 (mod 64) and columns
+//             x = 0 / 32 (mod 64) select them in): bit 0 the sweep passes it and the border goes on on both sides,
+//             bit 1 it also passed the east crack before it
+//   bits 12-13 dx + 1, bits 14-15 dy + 1 of the step
+// (the arithmetic version of the step was ~115 vector instructions, this one ~75).  A step's place in its group's
+// chain word is static; the window has its rows y - 1 and y + 1 next to row y at either end as well (18 physical rows:
+// row 0 repeats row 16, row 17 repeats row 1), so one address and two immediate offsets fetch the three rows; the two
+// words of a row are read by the word the neighbourhood starts in and the other one (address ^ 4), which a funnel shift
+// joins.  Steps per service phase, border stage of the bench scene / the photo scene in ms: 4: 4.29 / 8.15, 6: 4.16 /
+// 7.84, 8: 4.04 / 7.66 (more does not fit the 32-bit group of chain codes).
+constexpr int kWin2Rows = kWinRows + 2;
+constexpr int kTile2Words = kWin2Rows * 2 * 64;  // per wavefront
+#ifndef WALK2_STEPS
+#define WALK2_STEPS 8
+#endif
+constexpr int kWalk2Steps = WALK2_STEPS;        // steps between two service phases
+static_assert(kWalk2Steps >= 2 && kWalk2Steps <= 8, "a group's chain codes are one 32-bit word");
+constexpr int kWalk2Waves = 5;                  // wavefronts per workgroup (they share the step table): 53 KB of LDS, three workgroups per CU
+
+struct TileWin2 {
+    int gx, gy;  // as TileWin
+    __device__ __forceinline__ void invalidate() { gx = -(1 << 20); gy = 0; }
+    __device__ __forceinline__ bool near_edge(int x, int y) const {
+        // (a move leaves the pixel 16..47 columns and 4..11 rows inside the window)
+        // rows 3..12 of 16: one row of hysteresis either side of where a move puts the pixel (a border that runs along a
+        // piece boundary would otherwise move its window at every other step)
+        return !((unsigned)(x - gx * 32 - 12) < 40u && (unsigned)(y - gy * kPieceRows - 3) < 10u);
+    }
+    // the 3x3 neighbourhood of (x, y) lies inside the window
+    __device__ __forceinline__ bool covers(int x, int y) const {
+        return (unsigned)(x - gx * 32 - 1) < 62u && (unsigned)(y - gy * kPieceRows - 1) < (unsigned)(kWinRows - 2);
+    }
+    // Move the window so that (x, y) is 16..47 columns and 4..11 rows inside it: only the pieces the new window does
+    // not share with the old one are loaded.  Word index of (physical row p, lane, column word w): (p * 64 + lane) * 2 + w.
+    // (Letting the lanes walk on in the old window while the loads are under way and committing them a phase later
+    // keeps 32 more registers alive, 136 in all, and was slower: 5.6 against 4.3 ms for the border stage even when
+    // capped at 128.  The wavefronts are not waiting for memory: SQ_WAIT_INST_ANY is a tenth of their cycles.)
+    __device__ __forceinline__ void recentre(const uint32_t* __restrict__ plane, int WS, int H, int x, int y,
+                                             uint32_t* __restrict__ tile, int lane) {
+        const int ngx = (x - 16) >> 5, ngy = (y - kPieceRows / 2) >> kPL;
+        const int pieceRows = plane_hb(H) << (5 - kPL);
+        const int dx = ngx - gx, dy = ngy - gy;
+        uint4 v[4][kPieceRows / 4];
+        bool fresh[4];
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const int i = p & 1, j = p >> 1;
+            fresh[p] = (unsigned)(dx + i) > 1u || (unsigned)(dy + j) > 1u;
+            if (fresh[p]) {
+                const int hx = min(max(ngx + i, 0), WS - 1), hy = min(max(ngy + j, 0), pieceRows - 1);
+                const uint4* src = reinterpret_cast<const uint4*>(
+                    plane + (unsigned)(((hy >> (5 - kPL)) * WS + hx) * 32 + (hy & ((32 >> kPL) - 1)) * kPieceRows));
+#pragma unroll
+                for (int q = 0; q < kPieceRows / 4; q++) v[p][q] = src[q];
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            if (!fresh[p]) continue;
+            const int hx = ngx + (p & 1), hy = ngy + (p >> 1);
+            const int upper = hy & 1;
+            uint32_t* dst = tile + (upper * kPieceRows + 1) * 128 + lane * 2 + (hx & 1);
+#pragma unroll
+            for (int q = 0; q < kPieceRows / 4; q++) {
+                dst[(4 * q + 0) * 128] = v[p][q].x;
+                dst[(4 * q + 1) * 128] = v[p][q].y;
+                dst[(4 * q + 2) * 128] = v[p][q].z;
+                dst[(4 * q + 3) * 128] = v[p][q].w;
+            }
+            tile[(upper ? 0 : 17) * 128 + lane * 2 + (hx & 1)] = upper ? v[p][1].w : v[p][0].x;
+        }
+        gx = ngx;
+        gy = ngy;
+    }
+    // the three 3-bit fields of the neighbourhood of (x, y): rows y - 1, y, y + 1, bit 0 = column x - 1
+    __device__ __forceinline__ void fields(const uint32_t* __restrict__ tile, int lane, int x, int y, uint32_t& t, uint32_t& m, uint32_t& u) const {
+        const int xm = x - 1;
+        const uint32_t a = (uint32_t)(((y & (kWinRows - 1)) + 1) * 128 + lane * 2) + (((uint32_t)xm >> 5) & 1u), b = a ^ 1u;
+        t = __funnelshift_r(tile[a - 128], tile[b - 128], xm) & 7u;
+        m = __funnelshift_r(tile[a], tile[b], xm) & 7u;
+        u = __funnelshift_r(tile[a + 128], tile[b + 128], xm) & 7u;
+    }
+};
+
+// ring mask (bit d = neighbour in direction d) from the three fields
+__device__ __forceinline__ uint32_t ring_of_fields(uint32_t t, uint32_t m, uint32_t u) { return pack_mask(t, m, u); }
+
+__device__ __forceinline__ uint16_t walk_lut_entry(int idx) {
+    const uint32_t t = idx & 7, m = (idx >> 3) & 7, u = (idx >> 6) & 7;
+    const int s = idx >> 9;
+    const uint32_t M = pack_mask(t, m, u);
+    const int b0 = (s + 1) & 7;
+    const uint32_t rot = ((M >> b0) | (M << (8 - b0))) & 0xFFu;
+    const int j = __builtin_ctz(rot | 0x100u);
+    const int q = (s + 1 + j) & 7;
+    const int tEast = (0 - s) & 7;
+    const int east = (unsigned int)(tEast - 1) < (unsigned int)j ? 1 : 0;
+    uint32_t e = (uint32_t)q | ((uint32_t)east << 3);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int sd = k == 0 ? 4 : k == 1 ? 0 : k == 2 ? 2 : 6;
+        const int tSeed = (sd - s) & 7;
+        const bool passes = (unsigned int)(tSeed - 1) < (unsigned int)j;
+        const bool pass = passes && seed_supported(M, sd);
+        const bool eb = pass && east && tEast < tSeed;
+        e |= ((pass ? 1u : 0u) | (eb ? 2u : 0u)) << (4 + 2 * k);
+    }
+    e |= ((0x901Au >> (2 * q)) & 3u) << 12;
+    e |= ((0xA901u >> (2 * q)) & 3u) << 14;
+    return (uint16_t)e;
+}
+
 template <bool CANDS>
-__device__ __forceinline__ void seg_walk_items(const uint32_t* __restrict__ planes, const DetCfg& cfg,
-                                               const uint64_t* __restrict__ seeds, unsigned int seedCap,
-                                               const uint64_t* __restrict__ candLong, unsigned int candCap,
-                                               SegRec* __restrict__ seg, unsigned int segCap,
-                                               uint32_t* __restrict__ chain, Counters* __restrict__ ctr,
-                                               uint32_t* __restrict__ tile, unsigned int wave, unsigned int nWaves) {
-    const int lane = threadIdx.x;
+__device__ __forceinline__ void seg_walk_lean(const uint32_t* __restrict__ planes, const DetCfg& cfg,
+                                              const uint64_t* __restrict__ seeds, unsigned int seedCap,
+                                              const uint64_t* __restrict__ candLong, unsigned int candCap,
+                                              SegRec* __restrict__ seg, unsigned int segCap,
+                                              uint32_t* __restrict__ chain, Counters* __restrict__ ctr,
+                                              uint32_t* __restrict__ tile, const uint16_t* __restrict__ lut,
+                                              unsigned int wave, unsigned int nWaves) {
+    const int lane = threadIdx.x & 63;
     const unsigned int nSeeds = min(ctr->nSeeds, seedCap), nLong = min(ctr->nLong, candCap);
     const unsigned int nItems = min(nSeeds + nLong, segCap);
     const unsigned int base = CANDS ? nSeeds : 0u, nMine = CANDS ? nItems - min(nSeeds, nItems) : min(nSeeds, nItems);
@@ -901,180 +1028,208 @@ __device__ __forceinline__ void seg_walk_items(const uint32_t* __restrict__ plan
     const int H = cfg.H, W = cfg.W, WS = cfg.WS, S = cfg.nScales;
     const size_t perPlane = plane_words(H, WS);
 
-    // Lane state, kept in vector registers as plain integers so that the step below compiles to straight-line code
-    // with selects (per-lane booleans that live across iterations end up as scalar mask pairs, and every `if` on them
-    // as a chain of scalar mask instructions: that doubled the instruction count of a step).
-    //   st: 0 idle, 1 following a border, 2 segment complete (the service phase writes its record), 3 segment
-    //       complete and the lane goes on in a continuation segment
-    constexpr int isCand = CANDS ? 1 : 0;
-    int st = 0, isHole = 0, fresh = 0;
+    // Lane state, kept in vector registers as plain integers so that the steps compile to straight-line code with selects
+    // (per-lane booleans that live across iterations end up as scalar mask pairs, and every `if` on them as a chain of
+    // scalar mask instructions)
+    //   st: 0 idle, 1 following a border, 2 segment complete, 3 segment complete and the lane goes on in a continuation
+    int st = 0, isHole = 0;
     uint64_t c = 0, nextC = 0;
-    uint32_t nextI = ~0u;   // the item this lane takes up next (~0u: none fetched)
-    bool exhausted = false;  // the queue has nothing more for this lane
-    uint32_t id = 0, count = 0, total = 0, minAll = 0xFFFFFFFFu, minEast = 0xFFFFFFFFu, startPix = 0, state0 = 0, chAcc = 0;
+    uint32_t nextI = ~0u;
+    bool exhausted = false;
+    uint32_t id = 0, count = 0, total = 0, minAll = 0xFFFFFFFFu, minEast = 0xFFFFFFFFu, startPix = 0, state0 = 0;
     uint32_t endNext = kSegNone, endKey = 0;
+    // chain codes: grp = the (up to four) steps since the last service phase, 4 bits each from bit 0; acc = the steps
+    // before them that have not filled a word yet, flushed = steps of this segment already written or in acc's words
+    uint32_t grp = 0, count0 = 0;
+    uint64_t acc = 0;
     int startKey = 0, cx = 1, cy = 1, s = 0;
     const uint32_t* plane = planes;
-    TileWin win;
+    TileWin2 win;
     win.invalidate();
+    bool fresh = false;  // a start candidate that has not taken its start state yet
     WaveQueue queue;
     const unsigned int qBatch = spread_batch(nMine, nWaves, kWalkBatch);
     queue.start(wave, nWaves, nMine, qBatch);
 
-    // Everything that touches global memory or is rare -- writing a finished segment's record, taking up the next
-    // work item, moving a lane's window -- happens in a service phase every kService steps, for all lanes that need
-    // it at once: between two phases the wave runs kService lean steps (LDS and registers only).  A window is moved
-    // when its lane is within kService + 1 pixels of leaving it, so no lane can run out of window between phases.
-    constexpr int kService = 4;
-    for (unsigned int iter = 0;; iter++) {
-        if (iter % kService == 0) {
-            // ---- finished segments: record, continuation ----
-            if (st >= 2) {
-                uint32_t cont = 0, next = endNext;
-                bool goesOn = st == 3;
-                if (goesOn) {
-                    const unsigned int v = atomicAdd(&ctr->nVirt, 1u);
-                    // continuation ids count down from the top of the record list, work items up from its bottom
-                    if (v >= segCap - nItems) {
-                        atomicOr(&ctr->overflow, 512u);
-                        next = kSegNone;
-                        goesOn = false;
-                    } else {
-                        cont = segCap - 1u - v;
-                        next = cont;
-                    }
-                }
-                if ((count & 7) != 0) chain[(size_t)id * 32 + (((count - 1) >> 3) & 31)] = chAcc;
-                SegRec r;
-                r.next = next; r.len = count; r.minAll = minAll; r.minEast = minEast; r.chunk = id; r.start = startPix;
-                // where the border goes on, for k_seg_link: position and plane of the seed reached
-                r.pad0 = endKey;
-                r.pad1 = (uint32_t)(c >> 36);  // frame << 4 | hole << 3 | scale
-                seg[id] = r;
-                st = 0;
-                if (goesOn) {
-                    id = cont;
-                    count = 0;
-                    minAll = minEast = 0xFFFFFFFFu;
-                    startPix = (uint32_t)cx | ((uint32_t)cy << 16);
-                    chAcc = 0;
-                    st = 1;
+    for (;;) {
+        // ================= service phase =================
+        // ---- the steps of the last group join the segment's chain; a full word goes to memory ----
+        {
+            const uint32_t e = count - count0;          // steps of the group (0..kWalk2Steps)
+            const uint32_t at = count0 & 7u;            // their place in the word being filled
+            acc |= (uint64_t)grp << (4u * at);
+            if (at + e >= 8u) {                         // the word is full
+                chain[(size_t)id * 32 + ((count0 >> 3) & 31u)] = (uint32_t)acc;
+                acc >>= 32;
+            }
+            grp = 0;
+            count0 = count;
+        }
+        // ---- finished segments: record, continuation ----
+        if (st >= 2) {
+            uint32_t cont = 0, next = endNext;
+            bool goesOn = st == 3;
+            if (goesOn) {
+                const unsigned int v = atomicAdd(&ctr->nVirt, 1u);
+                if (v >= segCap - nItems) {
+                    atomicOr(&ctr->overflow, 512u);
+                    next = kSegNone;
+                    goesOn = false;
+                } else {
+                    cont = segCap - 1u - v;
+                    next = cont;
                 }
             }
-            // ---- lanes without a next item draw one (its load is in flight while the current item is followed) ----
-            {
-                const bool need = nextI == ~0u && !exhausted;
-                const unsigned int i = queue.pop<1>(need, head, nMine, qBatch, lane);
-                if (need) {
-                    if (i != ~0u) {
-                        nextI = base + i;
-                        nextC = CANDS ? candLong[i] : seeds[i];
-                    } else if (queue.empty()) {
-                        exhausted = true;
-                    }
-                }
-            }
-            // ---- idle lanes take up their next item ----
-            if (st == 0 && nextI != ~0u) {
-                c = nextC;
-                id = nextI;
-                nextI = ~0u;
-                const uint32_t pos = (uint32_t)(c & 0xFFFFFFFFull);
-                plane = planes + ((size_t)(uint32_t)(c >> 40) * S + (int)((c >> 36) & 7u)) * perPlane;
-                cy = row_of(cfg, pos);
-                cx = (int)pos - cy * W;
-                isHole = isCand & (int)((c >> 39) & 1u);
-                startKey = cy * W + cx;
+            if ((count & 7u) != 0u) chain[(size_t)id * 32 + (((count - 1u) >> 3) & 31u)] = (uint32_t)acc;
+            SegRec r;
+            r.next = next; r.len = count; r.minAll = minAll; r.minEast = minEast; r.chunk = id; r.start = startPix;
+            r.pad0 = endKey;
+            r.pad1 = (uint32_t)(c >> 36);  // frame << 4 | hole << 3 | scale
+            seg[id] = r;
+            st = 0;
+            if (goesOn) {
+                id = cont;
+                count = count0 = 0;
+                acc = 0;
                 minAll = minEast = 0xFFFFFFFFu;
-                if (!isCand) {
-                    const int d = seed_dir(cx, cy);
-                    s = d < 0 ? 4 : d;                   // as if that crack had just been swept
-                    if (d == 0) minEast = (uint32_t)startKey;  // an east seed: the crack itself is an east crack of the border
-                }
-                count = 0;
-                total = 0;
                 startPix = (uint32_t)cx | ((uint32_t)cy << 16);
-                chAcc = 0;
-                win.invalidate();
                 st = 1;
-                fresh = isCand;
-            }
-            if (!__any(st == 1)) {
-                if (__all(exhausted && nextI == ~0u)) break;
-                continue;
-            }
-            // ---- windows ----
-            if (__any(st == 1 && win.near_edge(cx, cy))) {
-                if (st == 1 && win.near_edge(cx, cy)) win.recentre(plane, WS, H, cx, cy, tile, lane);
             }
         }
-        if (st == 1 && win.covers(cx, cy)) {  // (always covered, see above; a lane that is not waits for the next phase)
-            const uint32_t m = win.mask(tile, lane, cx, cy);
-            // a start candidate takes its start state (P0, s0) (s0 is never -1: single pixels end in the short pass)
-            if constexpr (CANDS) {
-                const int s0 = fresh_dir(m, isHole != 0);
-                s = fresh ? (s0 < 0 ? 0 : s0) : s;
-                state0 = fresh ? pack_state(cx, cy, s) : state0;
-                fresh = 0;
+        // ---- idle lanes take up their next item ----
+        if (st == 0 && nextI != ~0u) {
+            c = nextC;
+            id = nextI;
+            nextI = ~0u;
+            const uint32_t pos = (uint32_t)(c & 0xFFFFFFFFull);
+            plane = planes + ((size_t)(uint32_t)(c >> 40) * S + (int)((c >> 36) & 7u)) * perPlane;
+            cy = row_of(cfg, pos);
+            cx = (int)pos - cy * W;
+            isHole = CANDS ? (int)((c >> 39) & 1u) : 0;
+            startKey = cy * W + cx;
+            minAll = minEast = 0xFFFFFFFFu;
+            if (!CANDS) {
+                const int d = seed_dir(cx, cy);
+                s = d < 0 ? 4 : d;                   // as if that crack had just been swept
+                if (d == 0) minEast = (uint32_t)startKey;  // an east seed: the crack itself is an east crack of the border
             }
-            // sweep counter-clockwise from s + 1 to the first foreground neighbour q; j background pixels are passed
-            const int b0 = (s + 1) & 7;
-            const uint32_t rot = ((m >> b0) | (m << (8 - b0))) & 0xFFu;
-            const int j = __builtin_ctz(rot | 0x100u);
-            const int q = (s + 1 + j) & 7;
-            // position of a direction in the sweep: passed when 1 <= t <= j
-            const int sd = seed_dir(cx, cy);
-            const int tSeed = (sd - s) & 7, tEast = (0 - s) & 7;
-            const int east = (unsigned int)(tEast - 1) < (unsigned int)j ? 1 : 0;
-            const uint32_t supA = (sd & 2) ? 0x38u : 0x0Eu, supB = (sd & 2) ? 0x83u : 0xE0u;  // both sides of the crack
-            const int atSeed = (sd >= 0 ? 1 : 0) & ((unsigned int)(tSeed - 1) < (unsigned int)j ? 1 : 0) & ((m & supA) ? 1 : 0) & ((m & supB) ? 1 : 0);
-            const uint32_t key = (uint32_t)(cy * W + cx);
-            // a start candidate that meets a crack with a smaller key is not the canonical start
-            const int abortNow = isCand & ((isHole ^ 1) | east) & ((int)key < startKey ? 1 : 0) & (atSeed ^ 1);
-            const int emit = (atSeed | abortNow) ^ 1;
-            // the seed's own segment accounts for the seed pixel, but it starts its sweep behind the crack: an east
-            // crack passed before the seed's crack in this same sweep is accounted for here
-            const int eastHere = (emit & east) | (atSeed & east & (tEast < tSeed ? 1 : 0));
-            minEast = eastHere ? min(minEast, key) : minEast;
-            minAll = emit ? min(minAll, key) : minAll;
-            chAcc |= emit ? (uint32_t)q << (4 * (count & 7)) : 0u;
-            if (emit && (count & 7) == 7) {
-                chain[(size_t)id * 32 + ((count >> 3) & 31)] = chAcc;
-                chAcc = 0;
+            count = count0 = 0;
+            total = 0;
+            acc = 0;
+            startPix = (uint32_t)cx | ((uint32_t)cy << 16);
+            win.invalidate();
+            st = 1;
+            fresh = CANDS;
+        }
+        // ---- lanes without a next item draw one: after the others have taken theirs up, so that this phase waits for no
+        //      load it has issued itself (the item is taken up a phase later at the earliest) ----
+        {
+            const bool need = nextI == ~0u && !exhausted;
+            const unsigned int i = queue.pop<1>(need, head, nMine, qBatch, lane);
+            if (need) {
+                if (i != ~0u) {
+                    nextI = base + i;
+                    nextC = CANDS ? candLong[i] : seeds[i];
+                } else if (queue.empty()) {
+                    exhausted = true;
+                }
             }
-            count += (uint32_t)emit;
-            total += (uint32_t)emit;
-            cx += emit ? dir_dx(q) : 0;
-            cy += emit ? dir_dy(q) : 0;
-            s = emit ? (q ^ 4) : s;
-            const int closed = emit & isCand & (pack_state(cx, cy, s) == state0 ? 1 : 0);  // a border without seeds closed
-            const int tooLong = emit & isCand & (total > (uint32_t)cfg.maxPerim ? 1 : 0) & (closed ^ 1);
-            const int full = emit & (count == (uint32_t)kSegLen ? 1 : 0) & ((closed | tooLong) ^ 1);
-            endNext = atSeed ? kSegPending : (abortNow | tooLong) ? kSegAbort : closed ? kSegSelf : endNext;
-            endKey = atSeed ? key : endKey;
-            st = (atSeed | abortNow | closed | tooLong) ? 2 : full ? 3 : 1;
+        }
+        if (!__any(st == 1)) {
+            if (__all(exhausted && nextI == ~0u)) break;
+            continue;
+        }
+        // ---- windows ----
+        if (__any(st == 1 && win.near_edge(cx, cy))) {
+            if (st == 1 && win.near_edge(cx, cy)) {
+                win.recentre(plane, WS, H, cx, cy, tile, lane);
+            }
+        }
+        // ---- a start candidate takes its start state (P0, s0) (s0 is never -1: single pixels end in the short pass) ----
+        if (CANDS && __any(fresh)) {
+            if (fresh) {
+                fresh = false;
+                uint32_t t, m, u;
+                win.fields(tile, lane, cx, cy, t, m, u);
+                const int s0 = fresh_dir(pack_mask(t, m, u), isHole != 0);
+                s = s0 < 0 ? 0 : s0;
+                state0 = pack_state(cx, cy, s);
+            }
+        }
+
+        // ================= kWalk2Steps steps =================
+#pragma unroll
+        for (int k = 0; k < kWalk2Steps; k++) {
+            // (after the service phase the pixel is at least three rows and twelve columns inside the window, so two
+            // steps are safe; from the third on a lane may have run out of window, and waits for the next phase)
+            const bool act = st == 1 && (k < 2 || win.covers(cx, cy));
+            if (act) {
+                uint32_t t, m, u;
+                win.fields(tile, lane, cx, cy, t, m, u);
+                const uint32_t L = lut[t | (m << 3) | (u << 6) | ((uint32_t)s << 9)];
+                const uint32_t q = L & 7u, east = (L >> 3) & 1u;
+                // the crack a seed can sit on here: rows 0 / 32 (mod 64) west / east, columns 0 / 32 (mod 64) north / south
+                const uint32_t fr = (L >> (4u + 2u * (((uint32_t)cy >> 5) & 1u))) & 3u;
+                const uint32_t fc = (L >> (8u + 2u * (((uint32_t)cx >> 5) & 1u))) & 3u;
+                const uint32_t f = (cy & 31) == 0 ? fr : (cx & 31) == 0 ? fc : 0u;
+                const uint32_t atSeed = f & 1u;
+                const uint32_t key = (uint32_t)(cy * W + cx);
+                uint32_t stop = atSeed;  // no step: the segment ends at this pixel
+                if (CANDS) {
+                    // a start candidate that meets a crack with a smaller key is not the canonical start
+                    const uint32_t abortNow = ((uint32_t)(isHole ^ 1) | east) & ((int)key < startKey ? 1u : 0u) & (atSeed ^ 1u);
+                    stop |= abortNow;
+                    endNext = abortNow ? kSegAbort : endNext;
+                }
+                const bool emit = stop == 0u;
+                // (the seed's own segment accounts for the seed pixel, but it starts its sweep behind the crack: an east
+                // crack passed before the seed's crack in this same sweep is accounted for here)
+                const uint32_t eastHere = emit ? east : (f >> 1);
+                minEast = min(minEast, eastHere ? key : 0xFFFFFFFFu);
+                minAll = min(minAll, emit ? key : 0xFFFFFFFFu);
+                grp |= emit ? q << (4 * k) : 0u;
+                count += emit ? 1u : 0u;
+                cx += (int)((L >> 12) & 3u) - 1;   // (a lane that stops does not look at its position again)
+                cy += (int)((L >> 14) & 3u) - 1;
+                s = (int)(q ^ 4u);
+                endNext = atSeed ? kSegPending : endNext;
+                endKey = atSeed ? key : endKey;
+                int nst = emit ? (count == (uint32_t)kSegLen ? 3 : 1) : 2;
+                if (CANDS) {
+                    total += emit ? 1u : 0u;
+                    const bool closed = emit && pack_state(cx, cy, s) == state0;  // a border without seeds closed
+                    const bool tooLong = emit && total > (uint32_t)cfg.maxPerim && !closed;
+                    endNext = closed ? kSegSelf : tooLong ? kSegAbort : endNext;
+                    nst = (closed || tooLong) ? 2 : nst;
+                }
+                st = nst;
+            }
         }
     }
 }
 
-// Every fourth wave starts on the start candidates (a sixth of the items, but they come without a seed to stop at and
-// their tail is the longer one), all waves then take the seeds, and whoever is done helps with what is left of the
-// candidates.
-__global__ __launch_bounds__(64) void k_seg_walk(const uint32_t* __restrict__ planes, DetCfg cfg,
-                                                 const uint64_t* __restrict__ seeds, unsigned int seedCap,
-                                                 const uint64_t* __restrict__ candLong, unsigned int candCap,
-                                                 SegRec* __restrict__ seg, unsigned int segCap,
-                                                 uint32_t* __restrict__ chain, Counters* __restrict__ ctr) {
-    __shared__ __align__(8) uint32_t tile[kTileWords];
-    const unsigned int nCandWaves = (gridDim.x + 3u) / 4u;
-    const bool candFirst = (blockIdx.x & 3u) == 0u;
-    if (candFirst) seg_walk_items<true>(planes, cfg, seeds, seedCap, candLong, candCap, seg, segCap, chain, ctr, tile, blockIdx.x >> 2, nCandWaves);
-    // the seeds' static batches go to the other waves first: with little work (a frame or a few) the waves that start
-    // on the candidates then have no seeds of their own, and a frame's two longest chains run side by side
-    const unsigned int nOther = gridDim.x - nCandWaves;
-    const unsigned int seedWave = candFirst ? nOther + (blockIdx.x >> 2) : (blockIdx.x >> 2) * 3u + (blockIdx.x & 3u) - 1u;
-    seg_walk_items<false>(planes, cfg, seeds, seedCap, candLong, candCap, seg, segCap, chain, ctr, tile, seedWave, gridDim.x);
-    if (!candFirst) seg_walk_items<true>(planes, cfg, seeds, seedCap, candLong, candCap, seg, segCap, chain, ctr, tile, nCandWaves, nCandWaves);
+__global__ __launch_bounds__(64 * kWalk2Waves) void k_seg_walk2(const uint32_t* __restrict__ planes, DetCfg cfg,
+                                                               const uint64_t* __restrict__ seeds, unsigned int seedCap,
+                                                               const uint64_t* __restrict__ candLong, unsigned int candCap,
+                                                               SegRec* __restrict__ seg, unsigned int segCap,
+                                                               uint32_t* __restrict__ chain, Counters* __restrict__ ctr) {
+    __shared__ __align__(8) uint32_t tiles[kWalk2Waves][kTile2Words];
+    __shared__ uint16_t lut[4096];
+    for (int i = threadIdx.x; i < 4096; i += 64 * kWalk2Waves) lut[i] = walk_lut_entry(i);
+    __syncthreads();
+    uint32_t* const tile = tiles[threadIdx.x >> 6];
+    // Every fourth wave starts on the start candidates (a sixth of the items, but they come without a seed to stop at and
+    // their tail is the longer one), all waves then take the seeds, and whoever is done helps with what is left of the
+    // candidates.  The seeds' static batches go to the other waves first: with little work (a frame or a few) the waves
+    // that start on the candidates then have no seeds of their own, and a frame's two longest chains run side by side.
+    const unsigned int w = blockIdx.x * kWalk2Waves + (threadIdx.x >> 6), nW = gridDim.x * kWalk2Waves;
+    const unsigned int nCandWaves = (nW + 3u) / 4u;
+    const bool candFirst = (w & 3u) == 0u;
+    if (candFirst) seg_walk_lean<true>(planes, cfg, seeds, seedCap, candLong, candCap, seg, segCap, chain, ctr, tile, lut, w >> 2, nCandWaves);
+    const unsigned int nOther = nW - nCandWaves;
+    const unsigned int seedWave = candFirst ? nOther + (w >> 2) : (w >> 2) * 3u + (w & 3u) - 1u;
+    seg_walk_lean<false>(planes, cfg, seeds, seedCap, candLong, candCap, seg, segCap, chain, ctr, tile, lut, seedWave, nW);
+    if (!candFirst) seg_walk_lean<true>(planes, cfg, seeds, seedCap, candLong, candCap, seg, segCap, chain, ctr, tile, lut, nCandWaves, nCandWaves);
 }
 
 // Turn "goes on at the seed at (plane, position)" into that seed's id: one lane per record.
@@ -1490,8 +1645,8 @@ void launch_trace(const DetCfg& c, const DetBuffers& b, hipStream_t st) {
                        b.contours, b.contourCap, b.poolCap, b.tasks, b.taskCap, b.counters);
     debug_stage(st, "trace_short");
     // long borders: segments (persistent: single-wave workgroups, 8 KiB of LDS each), links, decision
-    hipLaunchKernelGGL(k_seg_walk, dim3(kTraceWaves), dim3(64), 0, st, b.planes, c, b.seeds, b.seedCap, b.candLong, b.candCap, b.seg,
-                       b.segCap, b.chain, b.counters);
+    hipLaunchKernelGGL(k_seg_walk2, dim3((kTraceWaves + kWalk2Waves - 1) / kWalk2Waves), dim3(64 * kWalk2Waves), 0, st, b.planes, c, b.seeds, b.seedCap,
+                       b.candLong, b.candCap, b.seg, b.segCap, b.chain, b.counters);
     debug_stage(st, "seg_walk");
     hipLaunchKernelGGL(k_seg_link, dim3(256 * 8), dim3(256), 0, st, b.seg, b.segCap, b.seedCap, b.candCap, c,
                        b.seeds, b.seedTable, b.counters);
