@@ -362,6 +362,22 @@ class Context:
                                                         d.shape[1], per_frame, _ptr(rvec), _ptr(tvec), _ptr(ok)))
         return rvec, tvec, ok
 
+    def fuse_moving_markers(self, n_frames, moving_ids, moving_sizes, want_poses=False):
+        """camsync_fuse_moving_markers on the frames of the detect_pnp / detect_pnp_frames call just before it: per
+        moving marker the mean world corners [M,4,3] over the cameras that located it, and how many did [M]
+        (with want_poses also the markers' aruco2cam rvec / tvec [B,M,3] and the located flags [B,M])."""
+        ids = np.ascontiguousarray(moving_ids, dtype=np.int32)
+        sizes = np.ascontiguousarray(moving_sizes, dtype=np.float64)
+        M = len(ids)
+        fused = np.zeros((M, 4, 3)); seen = np.zeros(M, np.int32)
+        rv = np.zeros((n_frames, M, 3)) if want_poses else None
+        tv = np.zeros((n_frames, M, 3)) if want_poses else None
+        loc = np.zeros((n_frames, M), np.uint8) if want_poses else None
+        self._check(self._lib.camsync_fuse_moving_markers(self._h, int(n_frames), _ptr(ids), _ptr(sizes), M, _ptr(fused), _ptr(seen),
+                                                          _ptr(rv) if want_poses else None, _ptr(tv) if want_poses else None,
+                                                          _ptr(loc) if want_poses else None))
+        return (fused, seen, rv, tv, loc) if want_poses else (fused, seen)
+
     def detect_pnp(self, frames, anchor_ids, anchor_obj, K, dist, max_markers: int = 64):
         f = self._frames(frames)
         B, H, W, Cn = f.shape

@@ -226,25 +226,21 @@ def PnP(image_points, object_points, mtx, dist, getMetrics=False):
     return rvec.reshape(3, 1), tvec.reshape(3, 1), metrics
 
 
-def _process_cameras_batched(fixedArucos, movingArucos, cameras, frames, metrics):
-    """processAruco(..., accept_none=True, directUpdate=False) for every (camera, frame) pair, with the GPU work of
-    all cameras in two launch sequences instead of two per camera: one detection + anchor PnP over all frames
-    (camsync_detect_pnp_frames, a camera matrix per frame) and one IPPE solve over all moving markers seen.
-    Same kernels and same inputs as the per-camera calls, so the results are identical; the cameras are updated in
-    order, and an error is raised where the per-camera loop would have raised it.
-    Returns one entry per camera: False, or (rvec, tvec, {id: aruco2world}, metrics_collected)."""
+def _detect_and_locate_cameras(fixedArucos, cameras, frames, after_batch=None):
+    """Detection + anchor PnP for every (camera, frame) pair, one launch sequence per frame size
+    (camsync_detect_pnp_frames, a camera matrix per frame).  Returns det: det[i] = (detected dict, rvec, tvec, ok, mae,
+    rmse) per camera.  after_batch(ctx, camera indices) is called after each batch, while the context still holds that
+    batch's detections and poses on the device (the next batch may run on the same context)."""
     n = len(cameras)
-    fixedArucos = list(fixedArucos)
-    movingArucos = list(movingArucos)
     fs = [_as_frame(f) for f in frames]
     anchor_ids = np.array([a.id for a in fixedArucos], dtype=np.int32)
     anchor_obj = (np.stack([a.getCornersAsList() for a in fixedArucos]).astype(np.float32)
                   if fixedArucos else np.zeros((0, 4, 3), np.float32))
-    det = [None] * n  # per camera: (detected dict, rvec, tvec, ok, mae, rmse)
-    groups = {}
+    det = [None] * n
+    by_shape = {}
     for i, f in enumerate(fs):
-        groups.setdefault(f.shape, []).append(i)
-    for shape, idx in groups.items():
+        by_shape.setdefault(f.shape, []).append(i)
+    for shape, idx in by_shape.items():
         ks = np.stack([np.asarray(cameras[i].mtx, np.float64).reshape(3, 3) for i in idx])
         nd = max(np.asarray(cameras[i].dist).size for i in idx)
         ds = np.zeros((len(idx), nd))
@@ -256,6 +252,39 @@ def _process_cameras_batched(fixedArucos, movingArucos, cameras, frames, metrics
         for k, i in enumerate(idx):
             found = {np.int32(ids[k, m]): corners[k, m].reshape(1, 4, 2).copy() for m in range(int(counts[k]))}
             det[i] = (found, rvec[k], tvec[k], int(ok[k]), float(mae[k]), float(rmse[k]))
+        if after_batch is not None:
+            after_batch(ctx, idx)
+    return det
+
+
+def _update_cameras(fixedArucos, cameras, det):
+    """The camera half of processAruco(accept_none=True) for every camera in order (aruco.py:317-336): the errors the
+    per-camera loop would raise, then Camera.updateWorldPosition.  Returns the indices of the cameras located."""
+    located = []
+    for i, cam in enumerate(cameras):
+        found, rvec, tvec, ok, _, _ = det[i]
+        if 4 * sum(1 for a in fixedArucos if found.get(a.id) is not None) < 4:
+            continue
+        if ok == 2:
+            raise _hip.CamsyncError(-1, "solvePnP needs at least 6 points when they are not coplanar (cv.error in the reference)")
+        if ok != 1:
+            raise Exception("Could not solve PnP")
+        cam.updateWorldPosition(rvec.reshape(3, 1), tvec.reshape(3, 1), noLowPassFilter=False)
+        located.append(i)
+    return located
+
+
+def _process_cameras_batched(fixedArucos, movingArucos, cameras, frames, metrics):
+    """processAruco(..., accept_none=True, directUpdate=False) for every (camera, frame) pair, with the GPU work of
+    all cameras in two launch sequences instead of two per camera: one detection + anchor PnP over all frames
+    (camsync_detect_pnp_frames, a camera matrix per frame) and one IPPE solve over all moving markers seen.
+    Same kernels and same inputs as the per-camera calls, so the results are identical; the cameras are updated in
+    order, and an error is raised where the per-camera loop would have raised it.
+    Returns one entry per camera: False, or (rvec, tvec, {id: aruco2world}, metrics_collected)."""
+    n = len(cameras)
+    fixedArucos = list(fixedArucos)
+    movingArucos = list(movingArucos)
+    det = _detect_and_locate_cameras(fixedArucos, cameras, frames)
     # the moving markers every located camera sees, in the order processAruco visits them
     pairs = []
     for i in range(n):
@@ -298,16 +327,50 @@ def _process_cameras_batched(fixedArucos, movingArucos, cameras, frames, metrics
     return out
 
 
+def _fuse_on_device(fixedArucos, movingArucos: dict, cameras, frames):
+    """processArucoFromMultipleCameras with the per-marker work on the device as well: after the batched detection +
+    anchor PnP, camsync_fuse_moving_markers locates every moving marker in every located camera, takes it to the world
+    frame and averages its corners over the cameras; one read-back of [markers,4,3] per frame size.  The host keeps
+    what is stateful: the cameras' poses and filtered positions, and the low-pass of Aruco.corners.
+    Returns {id: mean world corners [4,3]} for the markers at least one camera located."""
+    arucos = list(movingArucos.values())
+    ids = [a.id for a in arucos]
+    sizes = [float(a.size) for a in arucos]
+    parts = []  # per batch: (mean corners [M,4,3], cameras that located the marker [M])
+
+    def fuse(ctx, idx):
+        if arucos:
+            parts.append(ctx.fuse_moving_markers(len(idx), ids, sizes))
+
+    det = _detect_and_locate_cameras(fixedArucos, cameras, frames, after_batch=fuse)
+    _update_cameras(fixedArucos, cameras, det)
+    out = {}
+    for k, a in enumerate(arucos):
+        n = sum(int(seen[k]) for _, seen in parts)
+        if n == 0:
+            continue
+        if len(parts) == 1:  # one frame size: the device's mean is the result as it is
+            out[a.id] = parts[0][0][k]
+        else:
+            out[a.id] = sum(fused[k] * int(seen[k]) for fused, seen in parts) / n
+    return out
+
+
 def processArucoFromMultipleCameras(fixedArucos, movingArucos: dict, cameras, frame, getMetrics=False):
     """All cameras look at the same scene (aruco.py:407-470): every camera that sees enough anchors locates
     itself and the moving markers it sees; each moving marker's world corners are averaged over the cameras
-    and low-passed into Aruco.corners.  The per-camera loop of the reference (aruco.py:417) is one batch here
-    (_process_cameras_batched); the results are those of the loop."""
+    and low-passed into Aruco.corners.  The per-camera loop of the reference (aruco.py:417) is one batch here, and so
+    is the per-marker work (_fuse_on_device); the results are those of the loop (to rounding: 1e-12 relative)."""
     assert len(cameras) == len(frame)
     fixedArucos = list(fixedArucos)
     batchable = (0 < len(fixedArucos) <= 64 and len(cameras) > 0
                  and all(getattr(c, "mtx", None) is not None and getattr(c, "dist", None) is not None for c in cameras))
-    if batchable:
+    if batchable and not getMetrics:
+        for key, mean in _fuse_on_device(fixedArucos, movingArucos, cameras, frame).items():
+            for i, newPos in enumerate(mean):
+                movingArucos[key].corners[i].updatePos(newPos)
+        return
+    if batchable:  # (the pairwise disagreement metric wants every camera's corners: the IPPE poses come back to the host)
         results = _process_cameras_batched(fixedArucos, movingArucos.values(), cameras, frame, getMetrics)
     else:  # nothing to batch over, or more anchors than the fused kernel gathers: the reference's own loop
         results = [processAruco(fixedArucos, movingArucos.values(), cam, f, accept_none=True, directUpdate=False,

@@ -62,6 +62,15 @@ struct camsync_ctx {
 
     // last detect chunk (for the debug getters)
     int lastB = 0, lastH = 0, lastW = 0;
+    // the last camsync_detect_pnp_batch / _frames call, when it was one chunk: its detections and camera poses are still
+    // on the device for camsync_fuse_moving_markers (poseFrames = 0: nothing to fuse from)
+    int poseFrames = 0, poseNdist = 0, posePerFrameCam = 0;
+    // scratch of camsync_fuse_moving_markers, for fuseCap (frame, marker) entries and fuseCapM markers
+    size_t fuseCap = 0, fuseCapM = 0;
+    float* d_fCorners = nullptr;
+    double *d_fSize = nullptr, *d_fK = nullptr, *d_fDist = nullptr, *d_fRvec = nullptr, *d_fTvec = nullptr, *d_fFused = nullptr, *d_fSizes = nullptr;
+    uint8_t *d_fValid = nullptr, *d_fOk = nullptr, *d_fLocated = nullptr;
+    int32_t *d_fIds = nullptr, *d_fSeen = nullptr;
 
     // calibration
     CalibState cal{};
@@ -544,7 +553,7 @@ void camsync_destroy(camsync_ctx* c) {
                     c->d_umap, c->d_uout, c->d_in, c->d_bin, b.planes, b.gray, b.cand, b.candLong, b.contours, b.binIdx, b.pool, b.tasks, b.seeds, b.seg, b.seedTable, b.chain, b.copies, b.resolveLog, b.quads, b.persp, b.idList, b.idCount, b.selState, b.qcount, b.counters, b.markers,
                     b.outIds, b.outCorners, b.rawCorners, b.outCounts, b.outRejected, b.outRejCounts, c->d_dict, c->d_expTab,
                     c->d_obj, c->d_img, c->d_npts, c->d_K, c->d_dist, c->d_rvec, c->d_tvec, c->d_mae, c->d_rmse, c->d_ok,
-                    c->d_anchorIds, c->d_anchorObj, c->d_calObj, c->d_calImg, c->cal.intr, c->cal.ext, c->cal.intrTrial,
+                    c->d_anchorIds, c->d_anchorObj, c->d_fCorners, c->d_fSize, c->d_fK, c->d_fDist, c->d_fRvec, c->d_fTvec, c->d_fFused, c->d_fSizes, c->d_fValid, c->d_fOk, c->d_fLocated, c->d_fIds, c->d_fSeen, c->d_calObj, c->d_calImg, c->cal.intr, c->cal.ext, c->cal.intrTrial,
                     c->cal.extTrial, c->cal.viewBlocks, c->cal.viewBlocksTrial, c->cal.partial, c->cal.ticket,
                     c->d_calWork, c->d_focalRows, c->d_calOk, c->d_calK, c->d_calNpts};
     for (void* p : ptrs)
@@ -669,6 +678,7 @@ static int detect_impl(camsync_ctx* c, const uint8_t* frames, const uint8_t* con
         HIPCHK(c, hipMemcpyAsync(c->d_anchorIds, anchor_ids, sizeof(int32_t) * n_anchor, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->d_anchorObj, anchor_obj, sizeof(float) * n_anchor * 12, hipMemcpyHostToDevice, c->stream));
     }
+    c->poseFrames = 0;
     for (int b0 = 0; b0 < B; b0 += c->maxB) {
         const int nb = std::min(c->maxB, B - b0);
         const uint8_t* src = frame_ptrs ? nullptr : frames + (size_t)b0 * px * C;
@@ -736,6 +746,11 @@ static int detect_impl(camsync_ctx* c, const uint8_t* frames, const uint8_t* con
             }
         }
     }
+    if (withPose && B <= c->maxB) {
+        c->poseFrames = B;
+        c->poseNdist = ndist;
+        c->posePerFrameCam = per_frame_cam;
+    }
     return CAMSYNC_OK;
 }
 
@@ -764,6 +779,57 @@ int camsync_detect_pnp_frames(camsync_ctx* c, const uint8_t* const* frame_ptrs, 
     if (!frame_ptrs) return fail(c, CAMSYNC_E_ARG, "frame_ptrs is NULL");
     return detect_impl(c, nullptr, frame_ptrs, on_device, B, H, W, C, max_markers, ids, corners, counts, 0, nullptr, nullptr,
                        anchor_ids, anchor_obj, n_anchor, K, dist, ndist, per_frame_cam, rvec, tvec, pose_ok, mae, rmse, true);
+}
+
+int camsync_fuse_moving_markers(camsync_ctx* c, int n_frames, const int32_t* moving_ids, const double* moving_sizes, int n_moving,
+                                double* fused_corners, int32_t* seen, double* marker_rvec, double* marker_tvec, uint8_t* located) {
+    if (!c) return CAMSYNC_E_ARG;
+    if (n_frames < 1 || n_frames != c->poseFrames)
+        return fail(c, CAMSYNC_E_ARG, "camsync_fuse_moving_markers works on the frames of the camsync_detect_pnp_batch / _frames call just "
+                    "before it on this context (that call had %d frames in one chunk, this one names %d)", c->poseFrames, n_frames);
+    if (n_moving < 1 || n_moving > 1024 || !moving_ids || !moving_sizes || !fused_corners || !seen)
+        return fail(c, CAMSYNC_E_ARG, "1..1024 moving markers with ids and sizes, and the fused_corners / seen outputs, are required");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t E = (size_t)n_frames * n_moving, M = (size_t)n_moving;
+    if (E > c->fuseCap || M > c->fuseCapM) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        void* old[] = {c->d_fCorners, c->d_fSize, c->d_fK, c->d_fDist, c->d_fRvec, c->d_fTvec, c->d_fFused, c->d_fSizes, c->d_fValid, c->d_fOk,
+                       c->d_fLocated, c->d_fIds, c->d_fSeen};
+        for (void* p : old)
+            if (p) (void)hipFree(p);
+        c->fuseCap = c->fuseCapM = 0;
+        c->d_fCorners = nullptr; c->d_fSize = c->d_fK = c->d_fDist = c->d_fRvec = c->d_fTvec = c->d_fFused = c->d_fSizes = nullptr;
+        c->d_fValid = c->d_fOk = c->d_fLocated = nullptr; c->d_fIds = c->d_fSeen = nullptr;
+        const size_t nE = std::max<size_t>(E, 64), nM = std::max<size_t>(M, 16);
+        HIPCHK(c, dalloc(&c->d_fCorners, nE * 8));
+        HIPCHK(c, dalloc(&c->d_fSize, nE));
+        HIPCHK(c, dalloc(&c->d_fK, nE * 9));
+        HIPCHK(c, dalloc(&c->d_fDist, nE * 8));
+        HIPCHK(c, dalloc(&c->d_fRvec, nE * 3));
+        HIPCHK(c, dalloc(&c->d_fTvec, nE * 3));
+        HIPCHK(c, dalloc(&c->d_fValid, nE));
+        HIPCHK(c, dalloc(&c->d_fOk, nE));
+        HIPCHK(c, dalloc(&c->d_fLocated, nE));
+        HIPCHK(c, dalloc(&c->d_fFused, nM * 12));
+        HIPCHK(c, dalloc(&c->d_fSizes, nM));
+        HIPCHK(c, dalloc(&c->d_fIds, nM));
+        HIPCHK(c, dalloc(&c->d_fSeen, nM));
+        c->fuseCap = nE;
+        c->fuseCapM = nM;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_fIds, moving_ids, sizeof(int32_t) * M, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_fSizes, moving_sizes, sizeof(double) * M, hipMemcpyHostToDevice, c->stream));
+    launch_fuse_moving(c->buf.outIds, c->buf.outCorners, c->buf.outCounts, c->d_ok, c->d_rvec, c->d_tvec, n_frames, c->d_fIds, c->d_fSizes,
+                       n_moving, c->d_K, c->d_dist, c->poseNdist, c->posePerFrameCam, c->d_fCorners, c->d_fSize, c->d_fK, c->d_fDist,
+                       c->d_fValid, c->d_fRvec, c->d_fTvec, c->d_fOk, c->d_fFused, c->d_fSeen, c->d_fLocated, c->stream);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(fused_corners, c->d_fFused, sizeof(double) * M * 12, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(seen, c->d_fSeen, sizeof(int32_t) * M, hipMemcpyDeviceToHost, c->stream));
+    if (marker_rvec) HIPCHK(c, hipMemcpyAsync(marker_rvec, c->d_fRvec, sizeof(double) * E * 3, hipMemcpyDeviceToHost, c->stream));
+    if (marker_tvec) HIPCHK(c, hipMemcpyAsync(marker_tvec, c->d_fTvec, sizeof(double) * E * 3, hipMemcpyDeviceToHost, c->stream));
+    if (located) HIPCHK(c, hipMemcpyAsync(located, c->d_fLocated, E, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return CAMSYNC_OK;
 }
 
 int camsync_detect_pnp_resident(camsync_ctx* c, const uint8_t* d_frames, int B, int H, int W, int C,

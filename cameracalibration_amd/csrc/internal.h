@@ -286,6 +286,12 @@ void launch_gather_anchors(const int32_t* ids, const float* corners, const int32
 void launch_ippe(const float* corners, const double* size, int B, const double* K, const double* dist,
                  int ndist, int perFrameCam, double* rvec, double* tvec, uint8_t* ok, hipStream_t st);
 
+void launch_fuse_moving(const int32_t* ids, const float* corners, const int32_t* counts, const uint8_t* poseOk,
+                        const double* camRvec, const double* camTvec, int B, const int32_t* movingIds, const double* movingSizes,
+                        int M, const double* K, const double* dist, int ndist, int perFrameCam, float* eCorners, double* eSize,
+                        double* eK, double* eDist, uint8_t* eValid, double* mRvec, double* mTvec, uint8_t* mOk, double* fused,
+                        int32_t* seen, uint8_t* located, hipStream_t st);
+
 // chessboard corner candidates (k_chess.hip) and cornerSubPix on caller-supplied points (k_subpix.hip)
 void launch_chess(const uint8_t* in, int C, int B, int H, int W, int scale, uint8_t* gray, uint16_t* S, int32_t* R,
                   int* frameMax, int maxCand, int32_t* cand, int* counts, hipStream_t st);

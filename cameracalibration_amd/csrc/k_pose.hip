@@ -731,6 +731,78 @@ __global__ void k_ippe(const float* __restrict__ corners, const double* __restri
     if (okOut) okOut[f] = fin ? 1 : 0;
 }
 
+// ---- processArucoFromMultipleCameras' per-marker work on the device (aruco.py:417-470) ----
+// entry e = frame * nMoving + m: the image corners of moving marker m in that frame (the last of several detections
+// with that id: detectAruco's dictionary keeps the last, aruco.py:270-271), with the frame's camera, for k_ippe.
+// valid[e] = the frame's camera was located (its anchor PnP succeeded) and the marker was seen.
+__global__ void k_gather_moving(const int32_t* __restrict__ ids, const float* __restrict__ corners, const int32_t* __restrict__ counts,
+                                const uint8_t* __restrict__ poseOk, int B, const int32_t* __restrict__ movingIds,
+                                const double* __restrict__ movingSizes, int M, const double* __restrict__ K,
+                                const double* __restrict__ dist, int ndist, int perFrameCam, float* __restrict__ outCorners,
+                                double* __restrict__ outSize, double* __restrict__ outK, double* __restrict__ outDist,
+                                uint8_t* __restrict__ valid) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= B * M) return;
+    const int f = e / M, m = e - f * M;
+    const int n = min(max(counts[f], 0), kMaxMarkerOut);
+    int at = -1;
+    for (int i = 0; i < n; i++)
+        if (ids[(size_t)f * kMaxMarkerOut + i] == movingIds[m]) at = i;
+#pragma unroll
+    for (int k = 0; k < 8; k++) outCorners[(size_t)e * 8 + k] = at >= 0 ? corners[((size_t)f * kMaxMarkerOut + at) * 8 + k] : 0.f;
+    outSize[e] = movingSizes[m];
+    const double* Kf = K + (perFrameCam ? (size_t)f * 9 : 0);
+    for (int k = 0; k < 9; k++) outK[(size_t)e * 9 + k] = Kf[k];
+    for (int k = 0; k < 8; k++) outDist[(size_t)e * 8 + k] = k < ndist ? dist[(perFrameCam ? (size_t)f * ndist : 0) + k] : 0.0;
+    valid[e] = (at >= 0 && poseOk[f] == 1) ? 1 : 0;
+}
+
+// One lane per moving marker: aruco2world = cam2world @ aruco2cam for every camera that located it (cam2world = the
+// inverse of the camera's world2cam: R^T, -R^T t; Transform.invert / combine), applied to the marker's corners
+// (-s/2, s/2, 0), (s/2, s/2, 0), (s/2, -s/2, 0), (-s/2, -s/2, 0) (aruco.py:434-441), summed over the cameras in frame
+// order and divided by their number (np.mean(axis=0), aruco.py:468).
+__global__ void k_fuse_moving(const double* __restrict__ camRvec, const double* __restrict__ camTvec, int B, int M,
+                              const double* __restrict__ mRvec, const double* __restrict__ mTvec, const uint8_t* __restrict__ mOk,
+                              const uint8_t* __restrict__ valid, const double* __restrict__ movingSizes,
+                              double* __restrict__ fused, int32_t* __restrict__ seen, uint8_t* __restrict__ located) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const double h = movingSizes[m] / 2;
+    const double lx[4] = {-h, h, h, -h}, ly[4] = {h, h, -h, -h};
+    double acc[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) acc[i] = 0;
+    int cnt = 0;
+    for (int f = 0; f < B; f++) {
+        const int e = f * M + m;
+        const bool ok = valid[e] && mOk[e] == 1;
+        located[e] = ok ? 1 : 0;
+        if (!ok) continue;
+        double Rc[9], Rm[9];
+        rodrigues_v2m(camRvec + (size_t)f * 3, Rc, nullptr);
+        rodrigues_v2m(mRvec + (size_t)e * 3, Rm, nullptr);
+        const double* tc = camTvec + (size_t)f * 3;
+        const double* tm = mTvec + (size_t)e * 3;
+        // aruco2world: rotation Rc^T Rm, translation Rc^T tm - Rc^T tc
+        double Rw[9], tw[3];
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+#pragma unroll
+            for (int c2 = 0; c2 < 3; c2++) Rw[r * 3 + c2] = Rc[0 * 3 + r] * Rm[0 * 3 + c2] + Rc[1 * 3 + r] * Rm[1 * 3 + c2] + Rc[2 * 3 + r] * Rm[2 * 3 + c2];
+            const double inv_t = -(Rc[0 * 3 + r] * tc[0] + Rc[1 * 3 + r] * tc[1] + Rc[2 * 3 + r] * tc[2]);
+            tw[r] = Rc[0 * 3 + r] * tm[0] + Rc[1 * 3 + r] * tm[1] + Rc[2 * 3 + r] * tm[2] + inv_t;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+#pragma unroll
+            for (int r = 0; r < 3; r++) acc[k * 3 + r] += Rw[r * 3 + 0] * lx[k] + Rw[r * 3 + 1] * ly[k] + tw[r];
+        cnt++;
+    }
+    seen[m] = cnt;
+#pragma unroll
+    for (int i = 0; i < 12; i++) fused[(size_t)m * 12 + i] = cnt ? acc[i] / cnt : 0.0;
+}
+
 }  // namespace
 
 void launch_pnp(const PnpArgs& a, hipStream_t st) {
@@ -754,6 +826,20 @@ void launch_ippe(const float* corners, const double* size, int B, const double* 
     if (B <= 0) return;
     hipLaunchKernelGGL(k_ippe, dim3((B + 63) / 64), dim3(64), 0, st, corners, size, B, K, dist, ndist, perFrameCam, rvec,
                        tvec, ok);
+}
+
+void launch_fuse_moving(const int32_t* ids, const float* corners, const int32_t* counts, const uint8_t* poseOk,
+                        const double* camRvec, const double* camTvec, int B, const int32_t* movingIds, const double* movingSizes,
+                        int M, const double* K, const double* dist, int ndist, int perFrameCam, float* eCorners, double* eSize,
+                        double* eK, double* eDist, uint8_t* eValid, double* mRvec, double* mTvec, uint8_t* mOk, double* fused,
+                        int32_t* seen, uint8_t* located, hipStream_t st) {
+    const int E = B * M;
+    if (E <= 0) return;
+    hipLaunchKernelGGL(k_gather_moving, dim3((E + 63) / 64), dim3(64), 0, st, ids, corners, counts, poseOk, B, movingIds, movingSizes, M,
+                       K, dist, ndist, perFrameCam, eCorners, eSize, eK, eDist, eValid);
+    hipLaunchKernelGGL(k_ippe, dim3((E + 63) / 64), dim3(64), 0, st, eCorners, eSize, E, eK, eDist, 8, 1, mRvec, mTvec, mOk);
+    hipLaunchKernelGGL(k_fuse_moving, dim3((M + 63) / 64), dim3(64), 0, st, camRvec, camTvec, B, M, mRvec, mTvec, mOk, eValid, movingSizes,
+                       fused, seen, located);
 }
 
 }  // namespace camsync

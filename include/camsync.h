@@ -202,6 +202,21 @@ int camsync_pnp_batch_noalloc(camsync_ctx* ctx, const float* obj, const float* i
                               int per_frame_cam, double* rvec, double* tvec, uint8_t* ok,
                               double* mae, double* rmse);
 
+/* The per-marker half of processArucoFromMultipleCameras (aruco.py:417-470) for the cameras of ONE batch, on the
+ * device: works on the detections and camera poses that the camsync_detect_pnp_batch / camsync_detect_pnp_frames call
+ * just before it left on this context (n_frames must be that call's batch, which must have been one chunk:
+ * B <= max_batch).  For every frame whose camera was located (pose_ok == 1) and every moving marker it sees (the last
+ * of several detections with that id, as detectAruco's dictionary keeps it, aruco.py:270-271): the marker's pose by
+ * IPPE_SQUARE with that frame's camera (estimate_pose_single_markers, aruco.py:82-119), aruco2world = cam2world @
+ * aruco2cam (locateAruco, aruco.py:288-290), applied to the corners (-s/2, s/2, 0), (s/2, s/2, 0), (s/2, -s/2, 0),
+ * (-s/2, -s/2, 0) (aruco.py:434-441); per marker the mean over the cameras (np.mean(axis=0), aruco.py:468).
+ * fused_corners f64 [n_moving,4,3] (zero where seen == 0), seen i32 [n_moving] = cameras that located the marker;
+ * optional: marker_rvec / marker_tvec f64 [n_frames,n_moving,3] (aruco2cam) and located u8 [n_frames,n_moving].
+ * The caller keeps the stateful part, the low-pass filter of Aruco.corners (aruco.py:469-470, position.py:34-37). */
+int camsync_fuse_moving_markers(camsync_ctx* ctx, int n_frames, const int32_t* moving_ids, const double* moving_sizes,
+                                int n_moving, double* fused_corners, int32_t* seen, double* marker_rvec,
+                                double* marker_tvec, uint8_t* located);
+
 /* cv.solvePnP(SOLVEPNP_IPPE_SQUARE) for B squares (aruco.py:97-117 inside
  * estimate_pose_single_markers).  corners f32 [B,4,2] (TL,TR,BR,BL),
  * size f64 [B], K/dist as above. */

@@ -147,12 +147,12 @@ def test_multiple_cameras_batched_equals_the_per_camera_loop():
     sheet = getArucosFromPaper(1)
     fixed = [sheet[i] for i in (10, 11, 14, 15)]
 
-    def run(batched, sets=2):
+    def run(batched, sets=2, metrics=True):
         cs = copy.deepcopy(cams)
         moving = {k: copy.deepcopy(sheet[k]) for k in (12, 13)}
         for _ in range(sets):  # twice: the low-pass filters carry state from the first set to the second
             if batched:
-                processArucoFromMultipleCameras(fixed, moving, cs, frames, getMetrics=True)
+                processArucoFromMultipleCameras(fixed, moving, cs, frames, getMetrics=metrics)
             else:
                 seen = {}
                 for cam, f in zip(cs, frames):
@@ -184,9 +184,19 @@ def test_multiple_cameras_batched_equals_the_per_camera_loop():
         want = np.array([c.coords for c in ml[k].corners], float)
         assert np.array_equal(got, want)
         assert not np.array_equal(got, np.array([c.coords for c in sheet[k].corners], float))
+    # the per-marker work on the device as well (camsync_fuse_moving_markers; two frame sizes = two batches here):
+    # the cameras exactly, the fused corners to rounding (the device sums in another order than numpy's matmul)
+    cf, mf = run(True, metrics=False)
+    for a, b in zip(cf, cl):
+        assert np.array_equal(a.world_position.coords, b.world_position.coords)
+        assert hasattr(a, "world2cam") == hasattr(b, "world2cam")
+    for k in mf:
+        got = np.array([c.coords for c in mf[k].corners], float)
+        want = np.array([c.coords for c in ml[k].corners], float)
+        assert np.allclose(got, want, rtol=1e-12, atol=1e-10), (k, np.abs(got - want).max())
 
     # ---- against the oracle and the reference's golden pose: one set of frames from fresh state ----
-    c1, m1 = run(True, sets=1)
+    c1, m1 = run(True, sets=1, metrics=False)
     G = _data.goldens()["pic_2_pose"]
     seen = {}
     for cam, f, got in zip(cams, frames, c1):
@@ -379,3 +389,31 @@ def test_distributed_calibration_over_rccl_world_1(tmp_path):
     assert np.array_equal(r["K"], K1) and np.array_equal(r["d"], d1)
     assert np.array_equal(r["rv"], rv1) and np.array_equal(r["tv"], tv1)
     assert abs(rms1 - _oracle.calibrate(obj, img, (1920, 1080), True)[0]) < 1e-6
+
+
+def test_fuse_moving_markers_needs_the_pose_call_before_it():
+    """camsync_fuse_moving_markers works on what camsync_detect_pnp_batch / _frames left on the device: without such a
+    call, after a call of another batch size, or after a call that took several chunks, it refuses."""
+    from cameracalibration_amd import _hip
+
+    frame = _data.load_bgr("pic_2.png")
+    K, d = _data.calibration("Logitec_A_1280-720_0.npz")
+    ctx = _hip.Context(720, 1280, 2)
+    with pytest.raises(_hip.CamsyncError):
+        ctx.fuse_moving_markers(1, [12, 13], [80.0, 80.0])
+    anchors = [10, 11, 14, 15]
+    ctx.detect_pnp(np.stack([frame, frame]), anchors, _data.v1_anchor_points(anchors), K, d)
+    with pytest.raises(_hip.CamsyncError):
+        ctx.fuse_moving_markers(1, [12, 13], [80.0, 80.0])
+    fused, seen, rv, tv, loc = ctx.fuse_moving_markers(2, [12, 13, 40], [80.0, 80.0, 30.0], want_poses=True)
+    assert seen.tolist() == [2, 2, 0] and loc.tolist() == [[1, 1, 0], [1, 1, 0]] and not fused[2].any()
+    # both "cameras" saw the same frame: the mean is either camera's corners, and the markers' poses are IPPE's
+    oids, ocor, _ = _oracle.detect(frame)
+    for m, i in enumerate((12, 13)):
+        ok, orv, otv = _oracle.ippe_square(ocor[oids.tolist().index(i)], 80.0, K, d)
+        assert ok and np.allclose(rv[0, m], orv, rtol=1e-6, atol=1e-8) and np.allclose(tv[0, m], otv, rtol=1e-6, atol=1e-6)
+        assert np.array_equal(rv[0, m], rv[1, m])
+    ctx.detect_pnp(np.stack([frame, frame, frame]), anchors, _data.v1_anchor_points(anchors), K, d)  # two chunks
+    with pytest.raises(_hip.CamsyncError):
+        ctx.fuse_moving_markers(3, [12], [80.0])
+    ctx.close()
