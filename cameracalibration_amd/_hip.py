@@ -104,6 +104,9 @@ def load_library() -> C.CDLL:
         lib.camsync_debug_limit_capacity.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32]
         lib.camsync_debug_restore_capacity.argtypes = [vp]
         lib.camsync_debug_identify_all.argtypes = [vp, i32]
+        lib.camsync_debug_shrink_lists.argtypes = [vp, C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_uint]
+        lib.camsync_debug_regrown.argtypes = [vp]
+        lib.camsync_fuse_moving_markers.argtypes = [vp, i32, vp, vp, i32, vp, vp, vp, vp, vp]
         lib.camsync_pnp_batch.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, vp, vp, vp]
         lib.camsync_pnp_batch_noalloc.argtypes = lib.camsync_pnp_batch.argtypes
         lib.camsync_ippe_square_batch.argtypes = [vp, vp, vp, i32, vp, vp, i32, i32, vp, vp, vp]
@@ -300,6 +303,12 @@ class Context:
             self._check(n)
         assert n <= cap
         return np.sort(out[:n])
+
+    def debug_shrink_lists(self, starts=0, contours=0, points=0, tasks=0, seeds=0):
+        self._check(self._lib.camsync_debug_shrink_lists(self._h, int(starts), int(contours), int(points), int(tasks), int(seeds)))
+
+    def debug_regrown(self):
+        return int(self._lib.camsync_debug_regrown(self._h))
 
     def debug_identify_all(self, on=True):
         """Identify every quad candidate in the following calls (debug_quads then reports an id for each)."""

@@ -62,6 +62,7 @@ struct camsync_ctx {
 
     // last detect chunk (for the debug getters)
     int lastB = 0, lastH = 0, lastW = 0;
+    int regrown = 0;  // times a scratch list was doubled after an overflow (grow_lists)
     // the last camsync_detect_pnp_batch / _frames call, when it was one chunk: its detections and camera poses are still
     // on the device for camsync_fuse_moving_markers (poseFrames = 0: nothing to fuse from)
     int poseFrames = 0, poseNdist = 0, posePerFrameCam = 0;
@@ -359,15 +360,131 @@ int collect_timers(camsync_ctx* c, int lastStage) {
     return CAMSYNC_OK;
 }
 
+// The scratch lists of the detection (start candidates, contour records, contour points, store / copy tasks, border
+// seeds and segments) are sized per frame by rule of thumb at camsync_create; cv.aruco.detectMarkers has no such limits
+// (aruco.py:256-264).  A chunk that overflows one of them is therefore run again with the lists concerned doubled, until
+// it fits, the list's index range ends (2^31 entries; 2^25 seeds: ids are packed with marks above that) or the device
+// has no memory left -- only then does the call fail with CAMSYNC_E_CAPACITY.  The per-frame lists of quad candidates
+// (1024) and markers (64) are fixed: their overflow (bits 8, 32) is not grown away.
+constexpr unsigned int kGrowable = 1u | 2u | 4u | 64u | 512u;
+
+template <typename T>
+bool regrow(T*& ptr, size_t oldCount, size_t newCount) {
+    T* fresh = nullptr;
+    if (newCount <= oldCount || hipMalloc(reinterpret_cast<void**>(&fresh), newCount * sizeof(T)) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    (void)hipFree(ptr);
+    ptr = fresh;
+    return true;
+}
+
+// Doubles the lists named in `mask`; false when none of them could grow (then the overflow is final).
+bool grow_lists(camsync_ctx* c, unsigned int mask) {
+    if (c->allocContourCap) return false;  // capacities pinned by camsync_debug_limit_capacity (tests of the loud path)
+    if (!(mask & kGrowable) || (mask & ~kGrowable & ~128u)) return false;
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return false;
+    DetBuffers& b = c->buf;
+    auto twice = [](unsigned int cap, unsigned int ceiling) { return (unsigned int)std::min<unsigned long long>(2ull * cap, ceiling); };
+    bool grown = false;
+    if (mask & 1u) {
+        const unsigned int n = twice(b.candCap, 0x7FFFFFFFu);
+        // (two lists of one capacity: both or neither)
+        uint64_t* a = nullptr;
+        if (n > b.candCap && hipMalloc(reinterpret_cast<void**>(&a), (size_t)n * sizeof(uint64_t)) == hipSuccess) {
+            if (regrow(b.candLong, b.candCap, n)) {
+                (void)hipFree(b.cand);
+                b.cand = a;
+                b.candCap = n;
+                grown = true;
+            } else {
+                (void)hipFree(a);
+            }
+        }
+        (void)hipGetLastError();
+    }
+    if (mask & 2u) {
+        const unsigned int n = twice(b.contourCap, 0x7FFFFFFFu);
+        uint32_t* idx = nullptr;
+        if (n > b.contourCap && hipMalloc(reinterpret_cast<void**>(&idx), (size_t)n * 5 * sizeof(uint32_t)) == hipSuccess) {
+            if (regrow(b.contours, b.contourCap, n)) {
+                (void)hipFree(b.binIdx);
+                b.binIdx = idx;
+                b.contourCap = n;
+                grown = true;
+            } else {
+                (void)hipFree(idx);
+            }
+        }
+        (void)hipGetLastError();
+    }
+    if (mask & 4u) {
+        const unsigned int n = twice(b.poolCap, 0x7FFFFFFFu);
+        if (regrow(b.pool, b.poolCap, n)) { b.poolCap = n; grown = true; }
+    }
+    if (mask & 64u) {
+        const unsigned int n = twice(b.taskCap, 0x7FFFFFFFu);
+        CopyTask* cp = nullptr;
+        if (n > b.taskCap && hipMalloc(reinterpret_cast<void**>(&cp), (size_t)n * sizeof(CopyTask)) == hipSuccess) {
+            if (regrow(b.tasks, b.taskCap, n)) {
+                (void)hipFree(b.copies);
+                b.copies = cp;
+                b.taskCap = b.copyCap = n;
+                grown = true;
+            } else {
+                (void)hipFree(cp);
+            }
+        }
+        (void)hipGetLastError();
+    }
+    if (mask & 512u) {
+        const unsigned int nSeed = twice(b.seedCap, 0x01FFFFFFu), nSeg = (unsigned int)std::min<size_t>(2 * (size_t)nSeed, 0x03FFFFFFu);
+        uint64_t* sd = nullptr;
+        SegRec* sg = nullptr;
+        uint32_t* ch = nullptr;
+        if (nSeed > b.seedCap && hipMalloc(reinterpret_cast<void**>(&sd), (size_t)nSeed * sizeof(uint64_t)) == hipSuccess &&
+            hipMalloc(reinterpret_cast<void**>(&sg), (size_t)nSeg * sizeof(SegRec)) == hipSuccess &&
+            hipMalloc(reinterpret_cast<void**>(&ch), (size_t)nSeg * 32 * sizeof(uint32_t)) == hipSuccess) {
+            (void)hipFree(b.seeds); (void)hipFree(b.seg); (void)hipFree(b.chain);
+            b.seeds = sd; b.seg = sg; b.chain = ch;
+            b.seedCap = nSeed;
+            b.segCap = b.chainCap = nSeg;
+            grown = true;
+        } else {
+            if (sd) (void)hipFree(sd);
+            if (sg) (void)hipFree(sg);
+            if (ch) (void)hipFree(ch);
+        }
+        (void)hipGetLastError();
+    }
+    if (grown) c->regrown++;
+    return grown;
+}
+
+int overflow_error(camsync_ctx* c, const Counters& h) {
+    return fail(c, CAMSYNC_E_CAPACITY,
+                "detection scratch overflow (mask 0x%x: 1 starts, 2 contours, 4 points, 8 quads, 32 markers, 64 store/copy tasks, "
+                "128 bad contour record, 512 border seeds / segments); candidates %u contours %u points %u seeds %u segments %u copies %u",
+                h.overflow, h.nCand, h.nContours, h.nPool, h.nSeeds, h.nSeeds + h.nLong + h.nVirt, h.nCopy);
+}
+
+// The chunk's counters after everything enqueued for it has run.  0: it fits; 1: a list overflowed and has been grown,
+// run the chunk again; negative: error.
+int chunk_verdict(camsync_ctx* c) {
+    Counters h;
+    HIPCHK(c, hipMemcpyAsync(&h, c->buf.counters, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (!h.overflow) return 0;
+    if (grow_lists(c, h.overflow)) return 1;
+    return overflow_error(c, h);
+}
+
 int check_overflow(camsync_ctx* c) {
     Counters h;
     HIPCHK(c, hipMemcpyAsync(&h, c->buf.counters, sizeof h, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (h.overflow)
-        return fail(c, CAMSYNC_E_CAPACITY,
-                    "detection scratch overflow (mask 0x%x: 1 starts, 2 contours, 4 points, 8 quads, 32 markers, 64 store/copy tasks, "
-                    "128 bad contour record, 512 border seeds / segments); candidates %u contours %u points %u seeds %u segments %u copies %u",
-                    h.overflow, h.nCand, h.nContours, h.nPool, h.nSeeds, h.nSeeds + h.nLong + h.nVirt, h.nCopy);
+    if (h.overflow) return overflow_error(c, h);
     return CAMSYNC_OK;
 }
 
@@ -727,7 +844,11 @@ static int detect_impl(camsync_ctx* c, const uint8_t* frames, const uint8_t* con
             HIPCHK(c, hipMemcpyAsync(hRej, c->buf.outRejected, sizeof(float) * nb * kMaxRejectedOut * 8, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipMemcpyAsync(hRejCounts, c->buf.outRejCounts, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, c->stream));
         }
-        rc = check_overflow(c);  // synchronises the stream
+        rc = chunk_verdict(c);  // synchronises the stream
+        if (rc == 1) {          // a scratch list overflowed and has been doubled: this chunk again
+            b0 -= c->maxB;
+            continue;
+        }
         if (rc) return rc;
         rc = collect_timers(c, lastStage);
         if (rc) return rc;
@@ -853,7 +974,6 @@ int camsync_detect_pnp_resident(camsync_ctx* c, const uint8_t* d_frames, int B, 
     HIPCHK(c, hipMemcpyAsync(c->d_K, K, sizeof(double) * 9, hipMemcpyHostToDevice, c->stream));
     if (ndist) HIPCHK(c, hipMemcpyAsync(c->d_dist, dist, sizeof(double) * ndist, hipMemcpyHostToDevice, c->stream));
     const size_t px = (size_t)H * W;
-    unsigned int overflowSeen = 0;
     for (int b0 = 0; b0 < B; b0 += c->maxB) {
         const int nb = std::min(c->maxB, B - b0);
         rc = enqueue_detect(c, d_frames + (size_t)b0 * px * C, nb, H, W, C);
@@ -872,17 +992,15 @@ int camsync_detect_pnp_resident(camsync_ctx* c, const uint8_t* d_frames, int B, 
         launch_export_markers(c->buf, nb, max_markers, d_ids + (size_t)b0 * max_markers, d_corners + (size_t)b0 * max_markers * 8,
                               d_counts + b0, c->stream);
         // the scratch lists are reused by the next chunk: the stream orders that; overflow is checked per chunk
-        Counters h;
-        HIPCHK(c, hipMemcpyAsync(&h, c->buf.counters, sizeof h, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        overflowSeen |= h.overflow;
+        rc = chunk_verdict(c);
+        if (rc == 1) {  // a scratch list overflowed and has been doubled: this chunk again
+            b0 -= c->maxB;
+            continue;
+        }
+        if (rc) return rc;
         rc = collect_timers(c, 7);
         if (rc) return rc;
     }
-    if (overflowSeen)
-        return fail(c, CAMSYNC_E_CAPACITY,
-                    "detection scratch overflow (mask 0x%x: 1 starts, 2 contours, 4 points, 8 quads, 32 markers, 64 store/copy tasks, "
-                    "128 bad contour record, 512 border seeds / segments)", overflowSeen);
     return CAMSYNC_OK;
 }
 
@@ -902,6 +1020,54 @@ int camsync_debug_limit_capacity(camsync_ctx* c, unsigned int contours, unsigned
     }
     return CAMSYNC_OK;
 }
+
+int camsync_debug_shrink_lists(camsync_ctx* c, unsigned int starts, unsigned int contours, unsigned int points, unsigned int tasks,
+                               unsigned int seeds) {
+    if (!c || c->allocContourCap) return CAMSYNC_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    DetBuffers& b = c->buf;
+    // (smaller buffers, really: an overflow must find the lists' ends where the capacities say they are)
+    if (starts && starts < b.candCap) {
+        (void)hipFree(b.cand); (void)hipFree(b.candLong);
+        b.cand = b.candLong = nullptr;
+        b.candCap = starts;
+        HIPCHK(c, dalloc(&b.cand, b.candCap));
+        HIPCHK(c, dalloc(&b.candLong, b.candCap));
+    }
+    if (contours && contours < b.contourCap) {
+        (void)hipFree(b.contours); (void)hipFree(b.binIdx);
+        b.contours = nullptr; b.binIdx = nullptr;
+        b.contourCap = contours;
+        HIPCHK(c, dalloc(&b.contours, b.contourCap));
+        HIPCHK(c, dalloc(&b.binIdx, (size_t)b.contourCap * 5));
+    }
+    if (points && points < b.poolCap) {
+        (void)hipFree(b.pool);
+        b.pool = nullptr;
+        b.poolCap = points;
+        HIPCHK(c, dalloc(&b.pool, b.poolCap));
+    }
+    if (tasks && tasks < b.taskCap) {
+        (void)hipFree(b.tasks); (void)hipFree(b.copies);
+        b.tasks = nullptr; b.copies = nullptr;
+        b.taskCap = b.copyCap = tasks;
+        HIPCHK(c, dalloc(&b.tasks, b.taskCap));
+        HIPCHK(c, dalloc(&b.copies, b.copyCap));
+    }
+    if (seeds && seeds < b.seedCap) {
+        (void)hipFree(b.seeds); (void)hipFree(b.seg); (void)hipFree(b.chain);
+        b.seeds = nullptr; b.seg = nullptr; b.chain = nullptr;
+        b.seedCap = seeds;
+        b.segCap = b.chainCap = 2 * seeds;
+        HIPCHK(c, dalloc(&b.seeds, b.seedCap));
+        HIPCHK(c, dalloc(&b.seg, b.segCap));
+        HIPCHK(c, dalloc(&b.chain, (size_t)b.chainCap * 32));
+    }
+    return CAMSYNC_OK;
+}
+
+int camsync_debug_regrown(const camsync_ctx* c) { return c ? c->regrown : CAMSYNC_E_ARG; }
 
 int camsync_debug_identify_all(camsync_ctx* c, int on) {
     if (!c) return CAMSYNC_E_ARG;

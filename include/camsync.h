@@ -171,6 +171,15 @@ int camsync_debug_restore_capacity(camsync_ctx* ctx);
  * following calls identify every candidate, so that camsync_debug_quads reports an id for each. */
 int camsync_debug_identify_all(camsync_ctx* ctx, int on);
 
+/* The detection's scratch lists (start candidates, contour records, contour points, store / copy tasks, border seeds)
+ * are sized at camsync_create; a chunk that overflows one is run again with that list doubled (the reference's
+ * cv.aruco.detectMarkers has no such limits, aruco.py:256-264), and CAMSYNC_E_CAPACITY is left for a list that cannot
+ * grow any more.  camsync_debug_shrink_lists replaces the lists by smaller ones (entries; 0 = leave) so that tests can
+ * make that happen; camsync_debug_regrown counts the doublings since camsync_create. */
+int camsync_debug_shrink_lists(camsync_ctx* ctx, unsigned int starts, unsigned int contours, unsigned int points,
+                               unsigned int tasks, unsigned int seeds);
+int camsync_debug_regrown(const camsync_ctx* ctx);
+
 /* ---- pose ----------------------------------------------------------- */
 
 /* cv.solvePnP(ITERATIVE) followed by cv.solvePnPRefineLM, batched

@@ -14,13 +14,19 @@
  * imgproc findContours / approxPolyDP / cornerSubPix / warpPerspective,
  * calib3d solvePnP / calibrateCamera) from their documented behaviour.
  *
- * Pins:
+ * Pins (tests/test_oracle_goldens.py, tests/test_chessboard.py):
  *   P1  tests/golden/pic_{1,2}.png -> ids {10..15} + 96 corner floats, 1e-3 px
- *       (reference camera_sync/test_aruco.py:203-326)             PINNED
+ *       (reference camera_sync/test_aruco.py:203-326)                              PINNED
  *   P2  pic_2 + Logitec_A_1280-720_0.npz -> rvec/tvec, 1e-4
- *       (reference camera_sync/test_aruco.py:329-359)             PINNED
- *   IPPE_SQUARE numerics, calibrateCamera outputs, `rejected` list, output
- *   order, dictionary ids outside {10..15,20..47}:                parity unpinned
+ *       (reference camera_sync/test_aruco.py:329-359)                              PINNED
+ *   P3  Rodrigues both ways (reference camera_sync/test_referential.py)            PINNED
+ *   P4  dictionary ids 10..15, 20..47 from the reference's printable sheets        PINNED
+ *   P5  pics/calib/*.jpg -> calibration/robot_640-480_500.npz (chessboard corners,
+ *       cornerSubPix, calibrateCamera end to end)                                  PINNED
+ *   P6  pics/blender/calib/*.png -> calibration/blender_1920-1080_0.npz            PINNED
+ *   P7  dictionary ids 0..3 from pics/robot_calib (the v1 sheet's small markers)   PINNED
+ *   IPPE_SQUARE numerics, undistort pixels, YUYV conversion, the `rejected` list,
+ *   output order, dictionary ids 4..9, 16..19, 48, 49:                            parity unpinned
  */
 #ifndef CAMSYNC_ORACLE_H
 #define CAMSYNC_ORACLE_H

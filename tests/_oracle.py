@@ -11,7 +11,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
-LIB_PATH = os.path.join(ORACLE_DIR, "_build", "libcamsync_oracle.so")
+# (CAMSYNC_ORACLE_LIB: another build of the oracle, e.g. the sanitizer build of `make -C oracle asan`)
+LIB_PATH = os.environ.get("CAMSYNC_ORACLE_LIB") or os.path.join(ORACLE_DIR, "_build", "libcamsync_oracle.so")
 
 
 class OrcParams(C.Structure):

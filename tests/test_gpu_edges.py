@@ -337,3 +337,28 @@ def test_other_reference_photos_match_the_oracle(group):
     for s, k, n in zip(d["scale"].tolist(), d["start_key"].tolist(), d["length"].tolist()):
         assert np.array_equal(pts[off:off + n], want[(s, k, n)]), (s, k, n)
         off += n
+
+
+def test_overflowing_scratch_lists_grow_and_the_result_is_the_oracles():
+    """cv.aruco.detectMarkers has no capacity limits (aruco.py:256-264): a chunk that overflows one of the detection's
+    scratch lists is run again with that list doubled.  The lists are made tiny here (camsync_debug_shrink_lists), so
+    the reference's desk photo needs several doublings of every one of them; the results still equal the oracle's, and
+    the grown context keeps working (a second call needs no more doublings)."""
+    bgr = _data.load_bgr("pic_2.png")
+    K, d = _data.calibration("Logitec_A_1280-720_0.npz")
+    ctx = _hip.Context(720, 1280, 2)
+    ctx.debug_shrink_lists(starts=2048, contours=64, points=4096, tasks=64, seeds=256)
+    assert ctx.debug_regrown() == 0
+    _same_as_oracle(ctx, np.stack([bgr, bgr[::-1].copy()]))
+    n = ctx.debug_regrown()
+    assert n >= 5, n
+    _same_as_oracle(ctx, bgr[None])
+    assert ctx.debug_regrown() == n
+    # the path that leaves its results on the device re-runs its chunk as well
+    ctx2 = _hip.Context(720, 1280, 1)
+    ctx2.debug_shrink_lists(starts=2048, contours=64, points=4096, tasks=64, seeds=256)
+    anchors = [10, 11, 14, 15]
+    r = ctx2.detect_pnp(bgr, anchors, _data.v1_anchor_points(anchors), K, d)
+    G = _data.goldens()["pic_2_pose"]
+    assert r[5][0] == 1 and np.allclose(r[3][0], G["rvec"], atol=1e-4) and np.allclose(r[4][0], G["tvec"], atol=1e-4)
+    assert ctx2.debug_regrown() >= 5
