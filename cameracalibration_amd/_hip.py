@@ -106,6 +106,7 @@ def load_library() -> C.CDLL:
         lib.camsync_debug_identify_all.argtypes = [vp, i32]
         lib.camsync_debug_shrink_lists.argtypes = [vp, C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_uint]
         lib.camsync_debug_regrown.argtypes = [vp]
+        lib.camsync_last_extent.argtypes = [vp, vp, vp]
         lib.camsync_fuse_moving_markers.argtypes = [vp, i32, vp, vp, i32, vp, vp, vp, vp, vp]
         lib.camsync_pnp_batch.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, vp, vp, vp]
         lib.camsync_pnp_batch_noalloc.argtypes = lib.camsync_pnp_batch.argtypes
@@ -260,8 +261,24 @@ class Context:
         self._check(self._lib.camsync_gray_threshold(self._h, _ptr(f), 0, B, H, W, Cn, _ptr(gray), _ptr(binp)))
         return gray, binp
 
+    def last_extent(self):
+        """(markers, rejected): the largest unclamped per-frame counts of the last detection call."""
+        m = C.c_int32(0)
+        r = C.c_int32(0)
+        self._check(self._lib.camsync_last_extent(self._h, C.byref(m), C.byref(r)))
+        return int(m.value), int(r.value)
+
+    def _wider(self, max_markers, max_rejected=None):
+        """Output widths for a second call when a frame of the last one had more markers (rejected candidates) than
+        the outputs hold -- cv.aruco.detectMarkers returns all of them (aruco.py:256-264) -- or None."""
+        m, r = self.last_extent()
+        if m <= max_markers and (max_rejected is None or r <= max_rejected):
+            return None
+        return max(m, max_markers), (None if max_rejected is None else max(r, max_rejected))
+
     def detect(self, frames, max_markers: int = 64, max_rejected: int = 1024):
-        """Returns (ids [B,M], corners [B,M,4,2], counts [B], rejected [B,R,4,2], rej_counts [B])."""
+        """Returns (ids [B,M], corners [B,M,4,2], counts [B], rejected [B,R,4,2], rej_counts [B]).  M and R are at
+        least max_markers / max_rejected, and wider when a frame holds more (the call is then made a second time)."""
         f = self._frames(frames)
         B, H, W, Cn = f.shape
         ids = np.full((B, max_markers), -1, np.int32)
@@ -271,6 +288,9 @@ class Context:
         rejc = np.zeros(B, np.int32)
         self._check(self._lib.camsync_detect_batch(self._h, _ptr(f), 0, B, H, W, Cn, max_markers, _ptr(ids),
                                                    _ptr(corners), _ptr(counts), max_rejected, _ptr(rej), _ptr(rejc)))
+        wider = self._wider(max_markers, max_rejected)
+        if wider:
+            return self.detect(f, *wider)
         return ids, corners, counts, rej, rejc
 
     def debug_counts(self, frame=0):
@@ -392,7 +412,7 @@ class Context:
         B, H, W, Cn = f.shape
         anchor_ids = np.ascontiguousarray(anchor_ids, dtype=np.int32)
         anchor_obj = np.ascontiguousarray(anchor_obj, dtype=np.float32).reshape(len(anchor_ids), 4, 3)
-        K, d, per_frame = _cam(K, dist, B)
+        K0, K, d, per_frame = (K,) + _cam(K, dist, B)
         ids = np.full((B, max_markers), -1, np.int32)
         corners = np.zeros((B, max_markers, 4, 2), np.float32)
         counts = np.zeros(B, np.int32)
@@ -402,6 +422,9 @@ class Context:
             self._h, _ptr(f), 0, B, H, W, Cn, _ptr(anchor_ids), _ptr(anchor_obj), len(anchor_ids), _ptr(K), _ptr(d),
             d.shape[1], per_frame, max_markers, _ptr(ids), _ptr(corners), _ptr(counts), _ptr(rvec), _ptr(tvec),
             _ptr(ok), _ptr(mae), _ptr(rmse)))
+        wider = self._wider(max_markers)
+        if wider:
+            return self.detect_pnp(f, anchor_ids, anchor_obj, K0, dist, wider[0])
         return ids, corners, counts, rvec, tvec, ok, mae, rmse
 
     def detect_pnp_frames(self, frames, anchor_ids, anchor_obj, K, dist, max_markers: int = 64):
@@ -416,7 +439,7 @@ class Context:
         ptrs = (C.c_void_p * B)(*[f.ctypes.data for f in fs])
         anchor_ids = np.ascontiguousarray(anchor_ids, dtype=np.int32)
         anchor_obj = np.ascontiguousarray(anchor_obj, dtype=np.float32).reshape(len(anchor_ids), 4, 3)
-        K, d, per_frame = _cam(K, dist, B)
+        K0, K, d, per_frame = (K,) + _cam(K, dist, B)
         ids = np.full((B, max_markers), -1, np.int32)
         corners = np.zeros((B, max_markers, 4, 2), np.float32)
         counts = np.zeros(B, np.int32)
@@ -426,6 +449,9 @@ class Context:
             self._h, ptrs, 0, B, H, W, Cn, _ptr(anchor_ids), _ptr(anchor_obj), len(anchor_ids), _ptr(K), _ptr(d),
             d.shape[1], per_frame, max_markers, _ptr(ids), _ptr(corners), _ptr(counts), _ptr(rvec), _ptr(tvec),
             _ptr(ok), _ptr(mae), _ptr(rmse)))
+        wider = self._wider(max_markers)
+        if wider:
+            return self.detect_pnp_frames(fs, anchor_ids, anchor_obj, K0, dist, wider[0])
         return ids, corners, counts, rvec, tvec, ok, mae, rmse
 
     def detect_pnp_resident(self, d_frames_ptr, B, H, W, Cn, anchor_ids, anchor_obj, K, dist, max_markers,

@@ -62,6 +62,8 @@ struct camsync_ctx {
 
     // last detect chunk (for the debug getters)
     int lastB = 0, lastH = 0, lastW = 0;
+    int hostMarkerOut = 0, hostQuadCap = 0;  // strides the pinned host buffers h_ids / h_corners and h_rej were sized for
+    int lastMarkers = 0, lastRejected = 0;   // most markers / rejected candidates a frame of the last detection call had
     int regrown = 0;  // times a scratch list was doubled after an overflow (grow_lists)
     // the last camsync_detect_pnp_batch / _frames call, when it was one chunk: its detections and camera poses are still
     // on the device for camsync_fuse_moving_markers (poseFrames = 0: nothing to fuse from)
@@ -172,6 +174,8 @@ hipError_t dalloc(T** p, size_t n) {
 DetCfg make_cfg(const camsync_ctx* c, int H, int W) {
     const camsync_params& p = c->params;
     DetCfg g{};
+    g.quadCap = c->buf.quadCap;
+    g.markerOut = c->buf.markerOut;
     g.H = H;
     g.W = W;
     g.WS = (W + 31) / 32;
@@ -257,14 +261,28 @@ int ensure_gray(camsync_ctx* c) {
 
 int ensure_host_out(camsync_ctx* c, bool wantRejected) {
     const size_t B = (size_t)c->maxB;
-    if (!c->h_ids) {
-        HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_ids), sizeof(int32_t) * B * kMaxMarkerOut, hipHostMallocDefault));
-        HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_corners), sizeof(float) * B * kMaxMarkerOut * 8, hipHostMallocDefault));
+    const int mo = c->buf.markerOut, qc = c->buf.quadCap;
+    if (!c->h_counts) {
         HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_counts), sizeof(int32_t) * B, hipHostMallocDefault));
         HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_rejCounts), sizeof(int32_t) * B, hipHostMallocDefault));
     }
-    if (wantRejected && !c->h_rej)
-        HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_rej), sizeof(float) * B * kMaxRejectedOut * 8, hipHostMallocDefault));
+    if (c->hostMarkerOut != mo) {  // (the per-frame marker slots have grown: grow_lists)
+        if (c->h_ids) (void)hipHostFree(c->h_ids);
+        if (c->h_corners) (void)hipHostFree(c->h_corners);
+        c->h_ids = nullptr;
+        c->h_corners = nullptr;
+        c->hostMarkerOut = 0;
+        HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_ids), sizeof(int32_t) * B * mo, hipHostMallocDefault));
+        HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_corners), sizeof(float) * B * mo * 8, hipHostMallocDefault));
+        c->hostMarkerOut = mo;
+    }
+    if (wantRejected && c->hostQuadCap != qc) {
+        if (c->h_rej) (void)hipHostFree(c->h_rej);
+        c->h_rej = nullptr;
+        c->hostQuadCap = 0;
+        HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_rej), sizeof(float) * B * qc * 8, hipHostMallocDefault));
+        c->hostQuadCap = qc;
+    }
     return CAMSYNC_OK;
 }
 
@@ -365,8 +383,9 @@ int collect_timers(camsync_ctx* c, int lastStage) {
 // (aruco.py:256-264).  A chunk that overflows one of them is therefore run again with the lists concerned doubled, until
 // it fits, the list's index range ends (2^31 entries; 2^25 seeds: ids are packed with marks above that) or the device
 // has no memory left -- only then does the call fail with CAMSYNC_E_CAPACITY.  The per-frame lists of quad candidates
-// (1024) and markers (64) are fixed: their overflow (bits 8, 32) is not grown away.
-constexpr unsigned int kGrowable = 1u | 2u | 4u | 64u | 512u;
+// (1024 slots at first) and of accepted markers (64) grow the same way, to what the fullest frame of the chunk needs
+// (at least twice the size, at most kQuadCeiling: the selection keeps candidate indices in 16 bits).
+constexpr unsigned int kGrowable = 1u | 2u | 4u | 8u | 32u | 64u | 512u;
 
 template <typename T>
 bool regrow(T*& ptr, size_t oldCount, size_t newCount) {
@@ -381,7 +400,8 @@ bool regrow(T*& ptr, size_t oldCount, size_t newCount) {
 }
 
 // Doubles the lists named in `mask`; false when none of them could grow (then the overflow is final).
-bool grow_lists(camsync_ctx* c, unsigned int mask) {
+bool grow_lists(camsync_ctx* c, const Counters& h) {
+    const unsigned int mask = h.overflow;
     if (c->allocContourCap) return false;  // capacities pinned by camsync_debug_limit_capacity (tests of the loud path)
     if (!(mask & kGrowable) || (mask & ~kGrowable & ~128u)) return false;
     if (hipStreamSynchronize(c->stream) != hipSuccess) return false;
@@ -458,6 +478,49 @@ bool grow_lists(camsync_ctx* c, unsigned int mask) {
         }
         (void)hipGetLastError();
     }
+    const size_t B = (size_t)c->maxB;
+    if (mask & 8u) {
+        // per-frame quad candidates: the candidate records, their perspective maps, the identification's list, the
+        // selection's state, the rejected candidates reported, and the selection's working set beyond the LDS size
+        const int n = (int)std::min<unsigned long long>(std::max<unsigned long long>(2ull * b.quadCap, ((unsigned long long)h.needQuads + 63) & ~63ull), kQuadCeiling);
+        QuadRec* q = nullptr; double* pm = nullptr; uint32_t* il = nullptr; int16_t* ss = nullptr; float* rj = nullptr; uint8_t* sw = nullptr;
+        if (n > b.quadCap && hipMalloc(reinterpret_cast<void**>(&q), B * n * sizeof(QuadRec)) == hipSuccess &&
+            hipMalloc(reinterpret_cast<void**>(&pm), B * n * 10 * sizeof(double)) == hipSuccess &&
+            hipMalloc(reinterpret_cast<void**>(&il), B * n * sizeof(uint32_t)) == hipSuccess &&
+            hipMalloc(reinterpret_cast<void**>(&ss), B * 3 * n * sizeof(int16_t)) == hipSuccess &&
+            hipMalloc(reinterpret_cast<void**>(&rj), B * n * 8 * sizeof(float)) == hipSuccess &&
+            hipMalloc(reinterpret_cast<void**>(&sw), B * sel_work_bytes(n)) == hipSuccess) {
+            (void)hipFree(b.quads); (void)hipFree(b.persp); (void)hipFree(b.idList); (void)hipFree(b.selState); (void)hipFree(b.outRejected);
+            if (b.selWork) (void)hipFree(b.selWork);
+            b.quads = q; b.persp = pm; b.idList = il; b.selState = ss; b.outRejected = rj; b.selWork = sw;
+            b.quadCap = n;
+            grown = true;
+        } else {
+            void* fresh[] = {q, pm, il, ss, rj, sw};
+            for (void* p : fresh)
+                if (p) (void)hipFree(p);
+        }
+        (void)hipGetLastError();
+    }
+    if (mask & 32u) {
+        const int n = (int)std::min<unsigned long long>(std::max<unsigned long long>(2ull * b.markerOut, ((unsigned long long)h.needMarkers + 63) & ~63ull), (unsigned long long)b.quadCap);
+        MarkerRec* mk = nullptr; int32_t* oi = nullptr; float* oc = nullptr; float* rc = nullptr;
+        if (n > b.markerOut && hipMalloc(reinterpret_cast<void**>(&mk), B * n * sizeof(MarkerRec)) == hipSuccess &&
+            hipMalloc(reinterpret_cast<void**>(&oi), B * n * sizeof(int32_t)) == hipSuccess &&
+            hipMalloc(reinterpret_cast<void**>(&oc), B * n * 8 * sizeof(float)) == hipSuccess &&
+            hipMalloc(reinterpret_cast<void**>(&rc), B * n * 8 * sizeof(float)) == hipSuccess) {
+            (void)hipFree(b.markers); (void)hipFree(b.outIds); (void)hipFree(b.outCorners); (void)hipFree(b.rawCorners);
+            b.markers = mk; b.outIds = oi; b.outCorners = oc; b.rawCorners = rc;
+            b.markerOut = n;
+            b.markerCap = (unsigned)std::min<size_t>(B * n, 0x7FFFFFFFu);
+            grown = true;
+        } else {
+            void* fresh[] = {mk, oi, oc, rc};
+            for (void* p : fresh)
+                if (p) (void)hipFree(p);
+        }
+        (void)hipGetLastError();
+    }
     if (grown) c->regrown++;
     return grown;
 }
@@ -465,8 +528,10 @@ bool grow_lists(camsync_ctx* c, unsigned int mask) {
 int overflow_error(camsync_ctx* c, const Counters& h) {
     return fail(c, CAMSYNC_E_CAPACITY,
                 "detection scratch overflow (mask 0x%x: 1 starts, 2 contours, 4 points, 8 quads, 32 markers, 64 store/copy tasks, "
-                "128 bad contour record, 512 border seeds / segments); candidates %u contours %u points %u seeds %u segments %u copies %u",
-                h.overflow, h.nCand, h.nContours, h.nPool, h.nSeeds, h.nSeeds + h.nLong + h.nVirt, h.nCopy);
+                "128 bad contour record, 512 border seeds / segments); candidates %u contours %u points %u seeds %u segments %u copies %u; "
+                "quad candidates of the fullest frame %u (slots %d), markers %u (slots %d)",
+                h.overflow, h.nCand, h.nContours, h.nPool, h.nSeeds, h.nSeeds + h.nLong + h.nVirt, h.nCopy, h.needQuads, c->buf.quadCap,
+                h.needMarkers, c->buf.markerOut);
 }
 
 // The chunk's counters after everything enqueued for it has run.  0: it fits; 1: a list overflowed and has been grown,
@@ -476,7 +541,7 @@ int chunk_verdict(camsync_ctx* c) {
     HIPCHK(c, hipMemcpyAsync(&h, c->buf.counters, sizeof h, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (!h.overflow) return 0;
-    if (grow_lists(c, h.overflow)) return 1;
+    if (grow_lists(c, h)) return 1;
     return overflow_error(c, h);
 }
 
@@ -614,21 +679,24 @@ int camsync_create(camsync_ctx** out, int device, int max_h, int max_w, int max_
     HIPCHK(c, dalloc(&b.copies, b.copyCap));
     b.resolveWaves = (unsigned)std::min<size_t>(std::max<size_t>(B * 8, 64), 256 * 32);
     HIPCHK(c, dalloc(&b.resolveLog, (size_t)b.resolveWaves * kResolveLogHops * 64));
-    HIPCHK(c, dalloc(&b.quads, B * kQuadCap));
-    HIPCHK(c, dalloc(&b.persp, B * kQuadCap * 10));
-    HIPCHK(c, dalloc(&b.idList, B * kQuadCap));
+    b.quadCap = kQuadCap0;
+    b.markerOut = kMarkerOut0;
+    b.selWork = nullptr;  // (allocated with the lists once a frame has more than kQuadLds candidates)
+    HIPCHK(c, dalloc(&b.quads, B * b.quadCap));
+    HIPCHK(c, dalloc(&b.persp, B * b.quadCap * 10));
+    HIPCHK(c, dalloc(&b.idList, B * b.quadCap));
     HIPCHK(c, dalloc(&b.idCount, B * 2));
-    HIPCHK(c, dalloc(&b.selState, B * 3 * kQuadCap));
+    HIPCHK(c, dalloc(&b.selState, B * 3 * b.quadCap));
     b.identifyAll = 0;
     HIPCHK(c, dalloc(&b.qcount, B));
     HIPCHK(c, dalloc(&b.counters, 1));
-    b.markerCap = (unsigned)(B * kMaxMarkerOut);
+    b.markerCap = (unsigned)(B * b.markerOut);
     HIPCHK(c, dalloc(&b.markers, b.markerCap));
-    HIPCHK(c, dalloc(&b.outIds, B * kMaxMarkerOut));
-    HIPCHK(c, dalloc(&b.outCorners, B * kMaxMarkerOut * 8));
-    HIPCHK(c, dalloc(&b.rawCorners, B * kMaxMarkerOut * 8));
+    HIPCHK(c, dalloc(&b.outIds, B * b.markerOut));
+    HIPCHK(c, dalloc(&b.outCorners, B * b.markerOut * 8));
+    HIPCHK(c, dalloc(&b.rawCorners, B * b.markerOut * 8));
     HIPCHK(c, dalloc(&b.outCounts, B));
-    HIPCHK(c, dalloc(&b.outRejected, B * kMaxRejectedOut * 8));
+    HIPCHK(c, dalloc(&b.outRejected, B * b.quadCap * 8));
     HIPCHK(c, dalloc(&b.outRejCounts, B));
     HIPCHK(c, dalloc(&c->d_dict, 4 * 1024));  // the codes under the four rotations
     HIPCHK(c, dalloc(&c->d_expTab, 21 * 41));
@@ -667,7 +735,7 @@ void camsync_destroy(camsync_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DetBuffers& b = c->buf;
     void* ptrs[] = {c->d_chessGray, c->d_chessS, c->d_chessR, c->d_chessCand, c->d_chessMax, c->d_chessCount, c->d_spIn, c->d_spOut, c->d_spN,
-                    c->d_umap, c->d_uout, c->d_in, c->d_bin, b.planes, b.gray, b.cand, b.candLong, b.contours, b.binIdx, b.pool, b.tasks, b.seeds, b.seg, b.seedTable, b.chain, b.copies, b.resolveLog, b.quads, b.persp, b.idList, b.idCount, b.selState, b.qcount, b.counters, b.markers,
+                    c->d_umap, c->d_uout, c->d_in, c->d_bin, b.planes, b.gray, b.cand, b.candLong, b.contours, b.binIdx, b.pool, b.tasks, b.seeds, b.seg, b.seedTable, b.chain, b.copies, b.resolveLog, b.quads, b.persp, b.idList, b.idCount, b.selState, b.selWork, b.qcount, b.counters, b.markers,
                     b.outIds, b.outCorners, b.rawCorners, b.outCounts, b.outRejected, b.outRejCounts, c->d_dict, c->d_expTab,
                     c->d_obj, c->d_img, c->d_npts, c->d_K, c->d_dist, c->d_rvec, c->d_tvec, c->d_mae, c->d_rmse, c->d_ok,
                     c->d_anchorIds, c->d_anchorObj, c->d_fCorners, c->d_fSize, c->d_fK, c->d_fDist, c->d_fRvec, c->d_fTvec, c->d_fFused, c->d_fSizes, c->d_fValid, c->d_fOk, c->d_fLocated, c->d_fIds, c->d_fSeen, c->d_calObj, c->d_calImg, c->cal.intr, c->cal.ext, c->cal.intrTrial,
@@ -785,10 +853,7 @@ static int detect_impl(camsync_ctx* c, const uint8_t* frames, const uint8_t* con
     }
     HIPCHK(c, hipSetDevice(c->device));
     const size_t px = (size_t)H * W;
-    rc = ensure_host_out(c, rejected != nullptr);
-    if (rc) return rc;
-    int32_t *const hIds = c->h_ids, *const hCounts = c->h_counts, *const hRejCounts = c->h_rejCounts;
-    float *const hCorners = c->h_corners, *const hRej = c->h_rej;
+    c->lastMarkers = c->lastRejected = 0;
     if (withPose) {
         rc = ensure_pose_scratch(c, (size_t)c->maxB, anchor_points(n_anchor));
         if (rc) return rc;
@@ -798,6 +863,12 @@ static int detect_impl(camsync_ctx* c, const uint8_t* frames, const uint8_t* con
     c->poseFrames = 0;
     for (int b0 = 0; b0 < B; b0 += c->maxB) {
         const int nb = std::min(c->maxB, B - b0);
+        // (per chunk: the per-frame slots, and the pinned buffers with them, grow when a chunk overflows them)
+        rc = ensure_host_out(c, rejected != nullptr);
+        if (rc) return rc;
+        int32_t *const hIds = c->h_ids, *const hCounts = c->h_counts, *const hRejCounts = c->h_rejCounts;
+        float *const hCorners = c->h_corners, *const hRej = c->h_rej;
+        const size_t mo = (size_t)c->buf.markerOut, qc = (size_t)c->buf.quadCap;
         const uint8_t* src = frame_ptrs ? nullptr : frames + (size_t)b0 * px * C;
         const uint8_t* d_in = src;
         if (frame_ptrs) {  // separate frames (host or device) are gathered into the staging buffer
@@ -822,7 +893,7 @@ static int detect_impl(camsync_ctx* c, const uint8_t* frames, const uint8_t* con
             const size_t kOff = per_frame_cam ? (size_t)b0 : 0, kCnt = per_frame_cam ? (size_t)nb : 1;
             HIPCHK(c, hipMemcpyAsync(c->d_K, K + kOff * 9, sizeof(double) * 9 * kCnt, hipMemcpyHostToDevice, c->stream));
             if (ndist) HIPCHK(c, hipMemcpyAsync(c->d_dist, dist + kOff * ndist, sizeof(double) * ndist * kCnt, hipMemcpyHostToDevice, c->stream));
-            launch_gather_anchors(c->buf.outIds, c->buf.outCorners, c->buf.outCounts, nb, c->d_anchorIds, c->d_anchorObj,
+            launch_gather_anchors(c->buf.outIds, c->buf.outCorners, c->buf.outCounts, nb, c->buf.markerOut, c->d_anchorIds, c->d_anchorObj,
                                   n_anchor, anchor_points(n_anchor), c->d_obj, c->d_img, c->d_npts, c->stream);
             PnpArgs a{};
             a.obj = c->d_obj; a.img = c->d_img; a.npts = c->d_npts; a.B = nb; a.N = anchor_points(n_anchor);
@@ -837,11 +908,11 @@ static int detect_impl(camsync_ctx* c, const uint8_t* frames, const uint8_t* con
             if (mae) HIPCHK(c, hipMemcpyAsync(mae + b0, c->d_mae, sizeof(double) * nb, hipMemcpyDeviceToHost, c->stream));
             if (rmse) HIPCHK(c, hipMemcpyAsync(rmse + b0, c->d_rmse, sizeof(double) * nb, hipMemcpyDeviceToHost, c->stream));
         }
-        HIPCHK(c, hipMemcpyAsync(hIds, c->buf.outIds, sizeof(int32_t) * nb * kMaxMarkerOut, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(hCorners, c->buf.outCorners, sizeof(float) * nb * kMaxMarkerOut * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(hIds, c->buf.outIds, sizeof(int32_t) * nb * mo, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(hCorners, c->buf.outCorners, sizeof(float) * nb * mo * 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(hCounts, c->buf.outCounts, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, c->stream));
         if (rejected) {
-            HIPCHK(c, hipMemcpyAsync(hRej, c->buf.outRejected, sizeof(float) * nb * kMaxRejectedOut * 8, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(hRej, c->buf.outRejected, sizeof(float) * nb * qc * 8, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipMemcpyAsync(hRejCounts, c->buf.outRejCounts, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, c->stream));
         }
         rc = chunk_verdict(c);  // synchronises the stream
@@ -855,15 +926,17 @@ static int detect_impl(camsync_ctx* c, const uint8_t* frames, const uint8_t* con
         for (int f = 0; f < nb; f++) {
             const int n = std::min(hCounts[f], max_markers);
             counts[b0 + f] = n;
+            c->lastMarkers = std::max(c->lastMarkers, (int)hCounts[f]);
             for (int m = 0; m < n; m++) {
-                ids[(size_t)(b0 + f) * max_markers + m] = hIds[(size_t)f * kMaxMarkerOut + m];
-                memcpy(corners + ((size_t)(b0 + f) * max_markers + m) * 8, &hCorners[((size_t)f * kMaxMarkerOut + m) * 8], 8 * sizeof(float));
+                ids[(size_t)(b0 + f) * max_markers + m] = hIds[(size_t)f * mo + m];
+                memcpy(corners + ((size_t)(b0 + f) * max_markers + m) * 8, &hCorners[((size_t)f * mo + m) * 8], 8 * sizeof(float));
             }
             if (rejected && rej_counts) {
                 const int nr = std::min(hRejCounts[f], max_rejected);
                 rej_counts[b0 + f] = nr;
+                c->lastRejected = std::max(c->lastRejected, (int)hRejCounts[f]);
                 for (int m = 0; m < nr; m++)
-                    memcpy(rejected + ((size_t)(b0 + f) * max_rejected + m) * 8, &hRej[((size_t)f * kMaxRejectedOut + m) * 8], 8 * sizeof(float));
+                    memcpy(rejected + ((size_t)(b0 + f) * max_rejected + m) * 8, &hRej[((size_t)f * qc + m) * 8], 8 * sizeof(float));
             }
         }
     }
@@ -940,7 +1013,7 @@ int camsync_fuse_moving_markers(camsync_ctx* c, int n_frames, const int32_t* mov
     }
     HIPCHK(c, hipMemcpyAsync(c->d_fIds, moving_ids, sizeof(int32_t) * M, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_fSizes, moving_sizes, sizeof(double) * M, hipMemcpyHostToDevice, c->stream));
-    launch_fuse_moving(c->buf.outIds, c->buf.outCorners, c->buf.outCounts, c->d_ok, c->d_rvec, c->d_tvec, n_frames, c->d_fIds, c->d_fSizes,
+    launch_fuse_moving(c->buf.outIds, c->buf.outCorners, c->buf.outCounts, c->buf.markerOut, c->d_ok, c->d_rvec, c->d_tvec, n_frames, c->d_fIds, c->d_fSizes,
                        n_moving, c->d_K, c->d_dist, c->poseNdist, c->posePerFrameCam, c->d_fCorners, c->d_fSize, c->d_fK, c->d_fDist,
                        c->d_fValid, c->d_fRvec, c->d_fTvec, c->d_fOk, c->d_fFused, c->d_fSeen, c->d_fLocated, c->stream);
     HIPCHK(c, hipGetLastError());
@@ -978,7 +1051,7 @@ int camsync_detect_pnp_resident(camsync_ctx* c, const uint8_t* d_frames, int B, 
         const int nb = std::min(c->maxB, B - b0);
         rc = enqueue_detect(c, d_frames + (size_t)b0 * px * C, nb, H, W, C);
         if (rc) return rc;
-        launch_gather_anchors(c->buf.outIds, c->buf.outCorners, c->buf.outCounts, nb, c->d_anchorIds, c->d_anchorObj,
+        launch_gather_anchors(c->buf.outIds, c->buf.outCorners, c->buf.outCounts, nb, c->buf.markerOut, c->d_anchorIds, c->d_anchorObj,
                               n_anchor, anchor_points(n_anchor), c->d_obj, c->d_img, c->d_npts, c->stream);
         PnpArgs a{};
         a.obj = c->d_obj; a.img = c->d_img; a.npts = c->d_npts; a.B = nb; a.N = anchor_points(n_anchor);
@@ -1001,6 +1074,13 @@ int camsync_detect_pnp_resident(camsync_ctx* c, const uint8_t* d_frames, int B, 
         rc = collect_timers(c, 7);
         if (rc) return rc;
     }
+    return CAMSYNC_OK;
+}
+
+int camsync_last_extent(const camsync_ctx* c, int32_t* markers, int32_t* rejected) {
+    if (!c) return CAMSYNC_E_ARG;
+    if (markers) *markers = c->lastMarkers;
+    if (rejected) *rejected = c->lastRejected;
     return CAMSYNC_OK;
 }
 
@@ -1163,9 +1243,9 @@ int camsync_debug_quads(camsync_ctx* c, int frame, int max_quads, float* corners
     HIPCHK(c, hipSetDevice(c->device));
     int q = 0;
     HIPCHK(c, hipMemcpy(&q, c->buf.qcount + frame, sizeof q, hipMemcpyDeviceToHost));
-    q = std::min(q, kQuadCap);
+    q = std::min(q, c->buf.quadCap);
     std::vector<QuadRec> h(q);
-    if (q) HIPCHK(c, hipMemcpy(h.data(), c->buf.quads + (size_t)frame * kQuadCap, sizeof(QuadRec) * q, hipMemcpyDeviceToHost));
+    if (q) HIPCHK(c, hipMemcpy(h.data(), c->buf.quads + (size_t)frame * c->buf.quadCap, sizeof(QuadRec) * q, hipMemcpyDeviceToHost));
     for (int i = 0; i < q && i < max_quads; i++) {
         for (int k = 0; k < 8; k++) corners[i * 8 + k] = (float)h[i].c[k];
         if (scale) scale[i] = h[i].scale;

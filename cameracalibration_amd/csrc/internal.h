@@ -11,10 +11,13 @@
 namespace camsync {
 
 constexpr int kMaxScales = 8;
-constexpr int kQuadCap = 1024;     // quad candidates kept per frame (40 markers x 3 scales x border pairs fit)
-constexpr int kSelCap = 1024;      // selected candidates per frame
-constexpr int kMaxMarkerOut = 64;  // accepted markers per frame held on device
-constexpr int kMaxRejectedOut = kSelCap;
+// Per-frame lists: quad candidates (DetCfg::quadCap slots, also the rejected candidates reported) and accepted
+// markers (DetCfg::markerOut slots).  They start at the sizes below -- 40 markers x 3 scales x border pairs fit, and the
+// selection of a frame with up to kQuadLds candidates runs in LDS -- and double when a frame overflows them
+// (camsync_api.hip, grow_lists) up to kQuadCeiling: the selection keeps candidate indices in 16 bits.
+constexpr int kQuadCap0 = 1024, kMarkerOut0 = 64;
+constexpr int kQuadLds = 1024;
+constexpr int kQuadCeiling = 32768;
 constexpr int kMaxAnchors = 64;
 
 // Detection configuration, derived from camsync_params + frame size and passed
@@ -40,6 +43,8 @@ struct DetCfg {
     float relWin;
     double subpixEps;
     int dictN;
+    int quadCap;             // per-frame slots of the quad-candidate lists (multiple of 64)
+    int markerOut;           // per-frame slots of the accepted-marker outputs
 };
 
 // Bit planes are block-linear: a plane is a grid of WS x HB blocks, each block = 32 rows x 32 pixels =
@@ -165,6 +170,8 @@ struct Counters {
     alignas(128) unsigned int qWalk;     // work-queue heads of the segment walkers (seeds) and of the resolve pass
     alignas(128) unsigned int qResolve;
     alignas(128) unsigned int nBin[5 * 32];  // contours per length bin of the quad fit, one cache line each: nBin[32 k]
+    alignas(128) unsigned int needQuads;    // after overflow 8 / 32: the most quad candidates / accepted markers a frame had
+    alignas(128) unsigned int needMarkers;
     alignas(128) unsigned int pad;
 };
 
@@ -223,27 +230,30 @@ struct DetBuffers {
     unsigned int segCap;
     uint32_t* seedTable;  // seed -> id, one table per bit plane indexed by the seed's place on the grid lines (k_contours.hip)
     uint32_t* binIdx;    // [5][contourCap] contour indices by length bin (k_quad_bin)
-    QuadRec* quads;      // [B,kQuadCap]
+    QuadRec* quads;      // [B,quadCap]
     int* qcount;         // [B]
+    int quadCap;         // per-frame slots of quads, persp, idList, selState, outRejected
+    int markerOut;       // per-frame slots of outIds, outCorners, rawCorners
+    uint8_t* selWork;    // [B, sel_work_bytes(quadCap)] working set of k_select for frames with more than kQuadLds candidates, or null
     Counters* counters;
     MarkerRec* markers;  // compact accepted list
     unsigned int markerCap;
     // per-frame outputs
-    int32_t* outIds;     // [B,kMaxMarkerOut]
-    float* outCorners;   // [B,kMaxMarkerOut,8] final (sub-pixel) corners
-    float* rawCorners;   // [B,kMaxMarkerOut,8] integer corners before refinement
+    int32_t* outIds;     // [B,markerOut]
+    float* outCorners;   // [B,markerOut,8] final (sub-pixel) corners
+    float* rawCorners;   // [B,markerOut,8] integer corners before refinement
     int32_t* outCounts;  // [B]
-    float* outRejected;  // [B,kMaxRejectedOut,8]
+    float* outRejected;  // [B,quadCap,8]
     int32_t* outRejCounts;
     // tables
     const uint16_t* dict;   // dictN codes under each of the four rotations, [rotation][entry]
     uint4* resolveLog;      // [resolveWaves, kResolveLogHops, 64] records visited by k_resolve's first pass (chunk, start, len)
     unsigned int resolveWaves;  // waves of k_resolve (each owns a slice of the log)
-    double* persp;          // [B, kQuadCap, 10] inverse perspective map of every quad + usable flag (k_quad_persp)
-    uint32_t* idList;       // [B, kQuadCap] quads to identify (k_group): from the front the candidates selected by the grouping
+    double* persp;          // [B, quadCap, 10] inverse perspective map of every quad + usable flag (k_quad_persp)
+    uint32_t* idList;       // [B, quadCap] quads to identify (k_group): from the front the candidates selected by the grouping
                             // (quad index | 0xFFFF << 16), from the back their fall-backs (quad index | representative << 16)
     int* idCount;           // [B, 2] entries at the front / at the back
-    int16_t* selState;      // [B, 3, kQuadCap] k_group's order, selection flags and fall-back relation for the final k_select
+    int16_t* selState;      // [B, 3, quadCap] k_group's order, selection flags and fall-back relation for the final k_select
     int identifyAll;        // debug: identify every quad candidate, not only the ones the selection can ask for
     const float* expTab;    // [21][41] separable cornerSubPix weights
 };
@@ -260,6 +270,7 @@ void launch_identify(const DetCfg& c, const DetBuffers& b, int B, hipStream_t st
 void launch_select(const DetCfg& c, const DetBuffers& b, int B, hipStream_t st);
 void launch_group(const DetCfg& c, const DetBuffers& b, int B, hipStream_t st);
 void launch_subpix(const DetCfg& c, const DetBuffers& b, int B, hipStream_t st);
+size_t sel_work_bytes(int quadCap);
 void launch_export_markers(const DetBuffers& b, int B, int maxMarkers, int32_t* dIds, float* dCorners, int32_t* dCounts,
                            hipStream_t st);
 
@@ -280,13 +291,13 @@ struct PnpArgs {
     double* rmse;          // [B] or null
 };
 void launch_pnp(const PnpArgs& a, hipStream_t st);
-void launch_gather_anchors(const int32_t* ids, const float* corners, const int32_t* counts, int B,
+void launch_gather_anchors(const int32_t* ids, const float* corners, const int32_t* counts, int B, int markerOut,
                            const int32_t* anchorIds, const float* anchorObj, int nAnchor, int N,
                            float* obj, float* img, int32_t* npts, hipStream_t st);
 void launch_ippe(const float* corners, const double* size, int B, const double* K, const double* dist,
                  int ndist, int perFrameCam, double* rvec, double* tvec, uint8_t* ok, hipStream_t st);
 
-void launch_fuse_moving(const int32_t* ids, const float* corners, const int32_t* counts, const uint8_t* poseOk,
+void launch_fuse_moving(const int32_t* ids, const float* corners, const int32_t* counts, int markerOut, const uint8_t* poseOk,
                         const double* camRvec, const double* camTvec, int B, const int32_t* movingIds, const double* movingSizes,
                         int M, const double* K, const double* dist, int ndist, int perFrameCam, float* eCorners, double* eSize,
                         double* eK, double* eDist, uint8_t* eValid, double* mRvec, double* mTvec, uint8_t* mOk, double* fused,

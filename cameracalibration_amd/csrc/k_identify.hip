@@ -50,11 +50,11 @@ __global__ __launch_bounds__(64) void k_quad_persp(const QuadRec* __restrict__ q
     // (frame = the fast grid index: consecutive workgroups go to different XCDs, and a frame's first workgroup has most
     // of its quads -- with the batch index fast, the busy workgroups all landed on half of the XCDs)
     const int f = blockIdx.x;
-    const int nq = min(qcount[f], kQuadCap);
+    const int nq = min(qcount[f], cfg.quadCap);
     const int S = (cfg.markerSize + 2 * cfg.borderBits) * cfg.cellSize;
     const double S1 = (double)(float)(S - 1);
     for (int q = blockIdx.y * 64 + threadIdx.x; q < nq; q += gridDim.y * 64) {
-        const QuadRec* qr = &quads[(size_t)f * kQuadCap + q];
+        const QuadRec* qr = &quads[(size_t)f * cfg.quadCap + q];
         double A[8][9];
 #pragma unroll
         for (int r = 0; r < 4; r++) {
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(64) void k_quad_persp(const QuadRec* __restrict__ q
         mi[6] = (x[3] * x[7] - x[4] * x[6]) * id;
         mi[7] = (x[1] * x[6] - x[0] * x[7]) * id;
         mi[8] = (x[0] * x[4] - x[1] * x[3]) * id;
-        double* out = persp + ((size_t)f * kQuadCap + q) * 10;
+        double* out = persp + ((size_t)f * cfg.quadCap + q) * 10;
 #pragma unroll
         for (int i = 0; i < 9; i++) out[i] = ok ? mi[i] : 0.0;
         out[9] = ok ? 1.0 : 0.0;
@@ -142,8 +142,8 @@ __global__ __launch_bounds__(64 * kIdWaves) void k_identify(const uint8_t* __res
     const int f = blockIdx.x;  // (fast index: see k_quad_persp)
     // pass 0: every quad of the frame; 1: the candidates the grouping selected; 2: the fall-backs of the selected ones
     // that pass 1 found invalid (k_group lists both kinds)
-    const int nq = pass == 0 ? min(qcount[f], kQuadCap) : min(idCount[2 * f + pass - 1], kQuadCap);
-    const uint32_t* const list = idList + (size_t)f * kQuadCap;
+    const int nq = pass == 0 ? min(qcount[f], cfg.quadCap) : min(idCount[2 * f + pass - 1], cfg.quadCap);
+    const uint32_t* const list = idList + (size_t)f * cfg.quadCap;
     const int H = cfg.H, W = cfg.W;
     const int nb = cfg.markerSize + 2 * cfg.borderBits;
     const int cell = cfg.cellSize;
@@ -164,15 +164,15 @@ __global__ __launch_bounds__(64 * kIdWaves) void k_identify(const uint8_t* __res
         __syncthreads();  // (the previous round's phase 3 has read what phase 1 overwrites)
         // ---- phase 1, quad by quad in every wave: samples, histogram, mean / standard deviation ----
         for (int b = wave; b < nbq; b += kIdWaves) {  // (interleaved: a short list still occupies all the waves)
-            const uint32_t entry = pass == 0 ? (uint32_t)(base + b) : pass == 1 ? list[base + b] : list[kQuadCap - 1 - (base + b)];
+            const uint32_t entry = pass == 0 ? (uint32_t)(base + b) : pass == 1 ? list[base + b] : list[cfg.quadCap - 1 - (base + b)];
             const int q = (int)(entry & 0xFFFFu);
             if (lane == 0) s_quad[b] = q;
-            if (pass == 2 && quads[(size_t)f * kQuadCap + (entry >> 16)].valid) {
+            if (pass == 2 && quads[(size_t)f * cfg.quadCap + (entry >> 16)].valid) {
                 // the representative was identified: its fall-backs are never asked for
                 if (lane == 0) s_mode[b] = 3;
                 continue;
             }
-            const double* mp = persp + ((size_t)f * kQuadCap + q) * 10;
+            const double* mp = persp + ((size_t)f * cfg.quadCap + q) * 10;
             double mi[9];
 #pragma unroll
             for (int i = 0; i < 9; i++) mi[i] = mp[i];
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(64 * kIdWaves) void k_identify(const uint8_t* __res
         for (int b = wave; b < nbq; b += kIdWaves) {  // (interleaved: a short list still occupies all the waves)
             const int mode = s_mode[b];
             if (mode == 3) continue;
-            QuadRec* qr = &quads[(size_t)f * kQuadCap + s_quad[b]];
+            QuadRec* qr = &quads[(size_t)f * cfg.quadCap + s_quad[b]];
             uint64_t bitsMask;  // bit (y*nb+x) of the nb x nb grid
             if (mode) {
                 bitsMask = (mode == 1) ? ~0ull : 0ull;

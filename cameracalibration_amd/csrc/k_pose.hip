@@ -736,7 +736,7 @@ __global__ void k_ippe(const float* __restrict__ corners, const double* __restri
 // with that id: detectAruco's dictionary keeps the last, aruco.py:270-271), with the frame's camera, for k_ippe.
 // valid[e] = the frame's camera was located (its anchor PnP succeeded) and the marker was seen.
 __global__ void k_gather_moving(const int32_t* __restrict__ ids, const float* __restrict__ corners, const int32_t* __restrict__ counts,
-                                const uint8_t* __restrict__ poseOk, int B, const int32_t* __restrict__ movingIds,
+                                int markerOut, const uint8_t* __restrict__ poseOk, int B, const int32_t* __restrict__ movingIds,
                                 const double* __restrict__ movingSizes, int M, const double* __restrict__ K,
                                 const double* __restrict__ dist, int ndist, int perFrameCam, float* __restrict__ outCorners,
                                 double* __restrict__ outSize, double* __restrict__ outK, double* __restrict__ outDist,
@@ -744,12 +744,12 @@ __global__ void k_gather_moving(const int32_t* __restrict__ ids, const float* __
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= B * M) return;
     const int f = e / M, m = e - f * M;
-    const int n = min(max(counts[f], 0), kMaxMarkerOut);
+    const int n = min(max(counts[f], 0), markerOut);
     int at = -1;
     for (int i = 0; i < n; i++)
-        if (ids[(size_t)f * kMaxMarkerOut + i] == movingIds[m]) at = i;
+        if (ids[(size_t)f * markerOut + i] == movingIds[m]) at = i;
 #pragma unroll
-    for (int k = 0; k < 8; k++) outCorners[(size_t)e * 8 + k] = at >= 0 ? corners[((size_t)f * kMaxMarkerOut + at) * 8 + k] : 0.f;
+    for (int k = 0; k < 8; k++) outCorners[(size_t)e * 8 + k] = at >= 0 ? corners[((size_t)f * markerOut + at) * 8 + k] : 0.f;
     outSize[e] = movingSizes[m];
     const double* Kf = K + (perFrameCam ? (size_t)f * 9 : 0);
     for (int k = 0; k < 9; k++) outK[(size_t)e * 9 + k] = Kf[k];
@@ -813,11 +813,11 @@ void launch_pnp(const PnpArgs& a, hipStream_t st) {
     else hipLaunchKernelGGL(k_pnp<4>, grid, dim3(64), 0, st, a);
 }
 
-void launch_gather_anchors(const int32_t* ids, const float* corners, const int32_t* counts, int B,
+void launch_gather_anchors(const int32_t* ids, const float* corners, const int32_t* counts, int B, int markerOut,
                            const int32_t* anchorIds, const float* anchorObj, int nAnchor, int N, float* obj,
                            float* img, int32_t* npts, hipStream_t st) {
     if (B <= 0) return;
-    hipLaunchKernelGGL(k_gather_anchors, dim3((B + 63) / 64), dim3(64), 0, st, ids, corners, counts, B, kMaxMarkerOut,
+    hipLaunchKernelGGL(k_gather_anchors, dim3((B + 63) / 64), dim3(64), 0, st, ids, corners, counts, B, markerOut,
                        anchorIds, anchorObj, nAnchor, N, obj, img, npts);
 }
 
@@ -828,14 +828,14 @@ void launch_ippe(const float* corners, const double* size, int B, const double* 
                        tvec, ok);
 }
 
-void launch_fuse_moving(const int32_t* ids, const float* corners, const int32_t* counts, const uint8_t* poseOk,
+void launch_fuse_moving(const int32_t* ids, const float* corners, const int32_t* counts, int markerOut, const uint8_t* poseOk,
                         const double* camRvec, const double* camTvec, int B, const int32_t* movingIds, const double* movingSizes,
                         int M, const double* K, const double* dist, int ndist, int perFrameCam, float* eCorners, double* eSize,
                         double* eK, double* eDist, uint8_t* eValid, double* mRvec, double* mTvec, uint8_t* mOk, double* fused,
                         int32_t* seen, uint8_t* located, hipStream_t st) {
     const int E = B * M;
     if (E <= 0) return;
-    hipLaunchKernelGGL(k_gather_moving, dim3((E + 63) / 64), dim3(64), 0, st, ids, corners, counts, poseOk, B, movingIds, movingSizes, M,
+    hipLaunchKernelGGL(k_gather_moving, dim3((E + 63) / 64), dim3(64), 0, st, ids, corners, counts, markerOut, poseOk, B, movingIds, movingSizes, M,
                        K, dist, ndist, perFrameCam, eCorners, eSize, eK, eDist, eValid);
     hipLaunchKernelGGL(k_ippe, dim3((E + 63) / 64), dim3(64), 0, st, eCorners, eSize, E, eK, eDist, 8, 1, mRvec, mTvec, mOk);
     hipLaunchKernelGGL(k_fuse_moving, dim3((M + 63) / 64), dim3(64), 0, st, camRvec, camTvec, B, M, mRvec, mTvec, mOk, eValid, movingSizes,

@@ -119,8 +119,9 @@ __device__ __forceinline__ void finish_polygon(IPt* __restrict__ s_dst, int cnt,
     const double dx1 = q[1].x - q[0].x, dy1 = q[1].y - q[0].y, dx2 = q[2].x - q[0].x, dy2 = q[2].y - q[0].y;
     if (dx1 * dy2 - dy1 * dx2 < 0.0) { IPt t = q[1]; q[1] = q[3]; q[3] = t; }
     const int slot = atomicAdd(&qcount[rec.frame], 1);
-    if (slot >= kQuadCap) {
+    if (slot >= cfg.quadCap) {
         atomicOr(&ctr->overflow, 8u);
+        atomicMax(&ctr->needQuads, (unsigned int)slot + 1u);
         return;
     }
     QuadRec r;
@@ -132,7 +133,7 @@ __device__ __forceinline__ void finish_polygon(IPt* __restrict__ s_dst, int cnt,
     r.clen = n;
     r.id = -1;
     r.rot = 0;
-    quads[(size_t)rec.frame * kQuadCap + slot] = r;
+    quads[(size_t)rec.frame * cfg.quadCap + slot] = r;
 }
 
 __global__ __launch_bounds__(64) void k_quad_fit(const ContourRec* __restrict__ contours, const uint32_t* __restrict__ list,

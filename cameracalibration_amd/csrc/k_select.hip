@@ -80,18 +80,27 @@ __device__ bool marker_in_marker(const float* m1, const float* m2) {
            point_in_quad(m2, m1[4], m1[5]) > 0 && point_in_quad(m2, m1[6], m1[7]) > 0;
 }
 
-// NQ: capacity of the LDS working set.  Two instances run over every frame: the small one takes the frames with
-// up to 256 candidates (nearly all of them, at a quarter of the LDS), the large one the rest.
+// NQ: capacity of the LDS working set.  Three instances run over every frame: the small one takes the frames with
+// up to 256 candidates (nearly all of them, at a quarter of the LDS), the large one those with up to kQuadLds, and the
+// instance NQ = 0 the frames beyond that (a frame full of squares: cv.aruco.detectMarkers has no limit), with the same
+// working set in global memory (`work`, sel_work_bytes per frame) -- the same code, L2 latencies instead of LDS ones.
 // NT: threads per frame.  The phases are loops over candidates, pairs or groups that any number of wavefronts can
 // share; what depends on the order of the sequential algorithm (group bookkeeping, acceptance) runs on thread 0, from
-// what the others have laid out in LDS.  One wavefront per frame gives the best throughput when there are thousands of
-// frames with a few dozen candidates each; with hundreds of candidates per frame (4K frames, forty markers at three
-// scales) or few frames, a frame's chain of LDS round trips is the whole stage's time and four wavefronts share it.
+// what the others have laid out in the working set.  One wavefront per frame gives the best throughput when there are
+// thousands of frames with a few dozen candidates each; with hundreds of candidates per frame (4K frames, forty markers
+// at three scales) or few frames, a frame's chain of LDS round trips is the whole stage's time and four wavefronts share it.
 constexpr int kGroupRound = 16;  // candidates whose pair tests are laid out before thread 0 replays them
+
+// Bytes of the working set per candidate: corners 32, perimeter / centroid / bound 16, rank 4, eight index arrays 16,
+// six flag arrays 6; per block of 64 candidates kGroupRound masks; kGroupRound x 8 words naming the blocks with any bit.
+constexpr size_t kSelWorkPerQuad = 32 + 16 + 4 + 16 + 6;
+constexpr size_t sel_work_layout(int cap) {
+    return ((kSelWorkPerQuad * (size_t)cap + (size_t)kGroupRound * (cap / 64) * 8 + (size_t)kGroupRound * 8 * 8) + 255) & ~(size_t)255;
+}
 
 // MODE 0: everything in one launch (every candidate has been identified: the debug path).  MODE 1: order and grouping
 // only; lists what the identification has to look at and keeps the order, the selection flags and the fall-back
-// relation in `state` ([B][3][kQuadCap] shorts).  MODE 2: the rest (containment, acceptance, outputs) from that state
+// relation in `state` ([B][3][quadCap] shorts).  MODE 2: the rest (containment, acceptance, outputs) from that state
 // and the identification's results.
 template <int NQ, int NT, int MODE>
 __global__ __launch_bounds__(NT) void k_select(const QuadRec* __restrict__ quads, const int* __restrict__ qcount,
@@ -99,34 +108,89 @@ __global__ __launch_bounds__(NT) void k_select(const QuadRec* __restrict__ quads
                                                int32_t* __restrict__ outCounts, float* __restrict__ outRejected,
                                                int32_t* __restrict__ outRejCounts, MarkerRec* __restrict__ markers,
                                                unsigned int markerCap, Counters* __restrict__ ctr,
-                                               uint32_t* __restrict__ idList, int* __restrict__ idCount, int16_t* __restrict__ state) {
+                                               uint32_t* __restrict__ idList, int* __restrict__ idCount, int16_t* __restrict__ state,
+                                               uint8_t* __restrict__ work) {
     constexpr bool GROUP_ONLY = MODE == 1;
+    constexpr bool IN_LDS = NQ > 0;
+    constexpr int LQ = IN_LDS ? NQ : 64;  // (LDS arrays of the instance that does not use them: never touched, dropped)
     constexpr int NW = NT / 64;       // wavefronts
-    constexpr int NB = NQ / 64;       // blocks of 64 candidates
-    constexpr int PER = (NQ + NT - 1) / NT;  // candidates per thread
-    __shared__ float s_c[NQ][8];      // corners, sorted order
-    __shared__ float s_perim[NQ];
-    __shared__ float s_cenx[NQ], s_ceny[NQ], s_thr[NQ];  // centroid, and perimeter x minMarkerDistanceRate, of the sorted candidates
-    __shared__ int s_rank[NQ];
-    __shared__ short s_gid[NQ];
-    __shared__ short s_closeOf[NQ];   // representative this candidate is a fall-back of, or -1
-    __shared__ short s_id[NQ];
-    __shared__ uint8_t s_rot[NQ], s_valid[NQ], s_isSel[NQ];
-    __shared__ short s_sel[NQ];       // selected candidates (sorted indices)
-    __shared__ short s_parent[NQ], s_depth[NQ];
-    __shared__ uint8_t s_acc[NQ], s_was[NQ], s_seen[NQ];
-    __shared__ short s_use[NQ];       // candidate whose corners/id are reported for a selected entry
+    constexpr int NBS = LQ / 64;      // blocks of 64 candidates (LDS instances)
+    constexpr int NBWS = 1;           // 64-bit words naming blocks (LDS instances: at most 16 blocks)
+    constexpr int PER = IN_LDS ? (NQ + NT - 1) / NT : 8;  // candidates a thread ranks in one pass over the others
+    __shared__ float l_c[LQ][8];
+    __shared__ float l_perim[LQ];
+    __shared__ float l_cenx[LQ], l_ceny[LQ], l_thr[LQ];
+    __shared__ int l_rank[LQ];
+    __shared__ short l_gid[LQ];
+    __shared__ short l_closeOf[LQ];
+    __shared__ short l_id[LQ];
+    __shared__ uint8_t l_rot[LQ], l_valid[LQ], l_isSel[LQ];
+    __shared__ short l_sel[LQ];
+    __shared__ short l_parent[LQ], l_depth[LQ];
+    __shared__ uint8_t l_acc[LQ], l_was[LQ], l_seen[LQ];
+    __shared__ short l_use[LQ];
+    __shared__ short l_orig[LQ];
+    __shared__ unsigned long long l_close[kGroupRound * NBS];
+    __shared__ unsigned long long l_closeBlocks[kGroupRound * NBWS];
     __shared__ int s_nGroups, s_nSel;
-    __shared__ short s_orig[NQ];      // index of the sorted candidate in the frame's quad list
     __shared__ int s_nList[2];
-    __shared__ unsigned long long s_close[kGroupRound][NB];  // per candidate of the round and block: the later candidates close to it
-    __shared__ uint32_t s_closeBlocks[kGroupRound];            // ... and which blocks have any
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int f = blockIdx.x;
-    const int n = min(qcount[f], kQuadCap);
-    if ((n > 256) != (NQ > 256)) return;  // the other instance's frame
-    const QuadRec* __restrict__ Q = quads + (size_t)f * kQuadCap;
+    const int quadCap = cfg.quadCap;
+    const int n = min(qcount[f], quadCap);
+    if ((n <= 256 ? 256 : n <= kQuadLds ? kQuadLds : 0) != NQ) return;  // another instance's frame
+
+    // the working set (the comments name the LDS instances' arrays; the third instance has them at `work`)
+    float (*s_c)[8];                  // corners, sorted order
+    float *s_perim, *s_cenx, *s_ceny, *s_thr;  // perimeter, centroid, and perimeter x minMarkerDistanceRate, of the sorted candidates
+    int* s_rank;
+    short *s_gid, *s_closeOf;         // group; representative this candidate is a fall-back of, or -1
+    short* s_id;
+    uint8_t *s_rot, *s_valid, *s_isSel;
+    short* s_sel;                     // selected candidates (sorted indices)
+    short *s_parent, *s_depth;
+    uint8_t *s_acc, *s_was, *s_seen;
+    short* s_use;                     // candidate whose corners/id are reported for a selected entry
+    short* s_orig;                    // index of the sorted candidate in the frame's quad list
+    unsigned long long* s_close;      // [kGroupRound][NB] per candidate of the round and block: the later candidates close to it
+    unsigned long long* s_closeBlocks;  // [kGroupRound][NBW] ... and which blocks have any
+    int NB, NBW;
+    if constexpr (IN_LDS) {
+        s_c = l_c; s_perim = l_perim; s_cenx = l_cenx; s_ceny = l_ceny; s_thr = l_thr; s_rank = l_rank; s_gid = l_gid;
+        s_closeOf = l_closeOf; s_id = l_id; s_rot = l_rot; s_valid = l_valid; s_isSel = l_isSel; s_sel = l_sel;
+        s_parent = l_parent; s_depth = l_depth; s_acc = l_acc; s_was = l_was; s_seen = l_seen; s_use = l_use; s_orig = l_orig;
+        s_close = l_close; s_closeBlocks = l_closeBlocks;
+        NB = NBS; NBW = NBWS;
+    } else {
+        const size_t Q = (size_t)quadCap;
+        uint8_t* w = work + (size_t)f * sel_work_layout(quadCap);
+        s_c = reinterpret_cast<float (*)[8]>(w); w += 32 * Q;
+        s_perim = reinterpret_cast<float*>(w); w += 4 * Q;
+        s_cenx = reinterpret_cast<float*>(w); w += 4 * Q;
+        s_ceny = reinterpret_cast<float*>(w); w += 4 * Q;
+        s_thr = reinterpret_cast<float*>(w); w += 4 * Q;
+        s_rank = reinterpret_cast<int*>(w); w += 4 * Q;
+        NB = quadCap / 64; NBW = 8;
+        s_close = reinterpret_cast<unsigned long long*>(w); w += (size_t)kGroupRound * NB * 8;
+        s_closeBlocks = reinterpret_cast<unsigned long long*>(w); w += (size_t)kGroupRound * NBW * 8;
+        s_gid = reinterpret_cast<short*>(w); w += 2 * Q;
+        s_closeOf = reinterpret_cast<short*>(w); w += 2 * Q;
+        s_id = reinterpret_cast<short*>(w); w += 2 * Q;
+        s_sel = reinterpret_cast<short*>(w); w += 2 * Q;
+        s_parent = reinterpret_cast<short*>(w); w += 2 * Q;
+        s_depth = reinterpret_cast<short*>(w); w += 2 * Q;
+        s_use = reinterpret_cast<short*>(w); w += 2 * Q;
+        s_orig = reinterpret_cast<short*>(w); w += 2 * Q;
+        s_rot = w; w += Q;
+        s_valid = w; w += Q;
+        s_isSel = w; w += Q;
+        s_acc = w; w += Q;
+        s_was = w; w += Q;
+        s_seen = w;
+    }
+
+    const QuadRec* __restrict__ Q = quads + (size_t)f * quadCap;
 
     if (n == 0) {
         if (tid == 0) {
@@ -136,7 +200,7 @@ __global__ __launch_bounds__(NT) void k_select(const QuadRec* __restrict__ quads
         return;
     }
 
-    int16_t* const st = state + (size_t)f * 3 * kQuadCap;  // [0]: quad index of the sorted candidate, [1]: selected, [2]: fall-back of
+    int16_t* const st = state + (size_t)f * 3 * quadCap;  // [0]: quad index of the sorted candidate, [1]: selected, [2]: fall-back of
     if (MODE == 2) {
         for (int r = tid; r < n; r += NT) {
             const int i = st[r];
@@ -145,8 +209,8 @@ __global__ __launch_bounds__(NT) void k_select(const QuadRec* __restrict__ quads
             s_id[r] = (short)Q[i].id;
             s_rot[r] = (uint8_t)Q[i].rot;
             s_valid[r] = (uint8_t)Q[i].valid;
-            s_isSel[r] = (uint8_t)st[kQuadCap + r];
-            s_closeOf[r] = st[2 * kQuadCap + r];
+            s_isSel[r] = (uint8_t)st[quadCap + r];
+            s_closeOf[r] = st[2 * quadCap + r];
         }
         __syncthreads();
     } else {
@@ -161,33 +225,37 @@ __global__ __launch_bounds__(NT) void k_select(const QuadRec* __restrict__ quads
         s_rank[i] = (int)((Q[i].scale << 24) | (0xFFFFFFu - (Q[i].scanKey & 0xFFFFFFu)));
     }
     __syncthreads();
-    // one pass over the candidates for all of a thread's own (up to PER) candidates: the two LDS reads of a step
-    // are shared by them, and successive steps do not depend on one another
-    int myRank[PER];
-    float myPerim[PER];
-    uint32_t myKey[PER];
-#pragma unroll
-    for (int t = 0; t < PER; t++) {
-        const int i = min(tid + NT * t, n - 1);
-        myRank[t] = 0;
-        myPerim[t] = s_perim[i];
-        myKey[t] = (uint32_t)s_rank[i];
-    }
-    for (int j = 0; j < n; j++) {
-        const float pj = s_perim[j];
-        const uint32_t kj = (uint32_t)s_rank[j];
+    // one pass over the candidates for (up to PER) candidates of the thread's own: the two reads of a step are shared
+    // by them, and successive steps do not depend on one another.  (The LDS instances need one pass.)  The ranks go
+    // to s_cenx (as bits) until every thread is done with the keys in s_rank.
+    for (int base = 0; base < n; base += NT * PER) {
+        int myRank[PER];
+        float myPerim[PER];
+        uint32_t myKey[PER];
 #pragma unroll
         for (int t = 0; t < PER; t++) {
-            if (NT * t >= n) break;  // (uniform)
-            // j comes before i (never true for j == i)
-            const bool before = (pj != myPerim[t]) ? pj > myPerim[t] : kj < myKey[t];
-            myRank[t] += before ? 1 : 0;
+            const int i = min(base + tid + NT * t, n - 1);
+            myRank[t] = 0;
+            myPerim[t] = s_perim[i];
+            myKey[t] = (uint32_t)s_rank[i];
         }
+        for (int j = 0; j < n; j++) {
+            const float pj = s_perim[j];
+            const uint32_t kj = (uint32_t)s_rank[j];
+#pragma unroll
+            for (int t = 0; t < PER; t++) {
+                if (base + NT * t >= n) break;  // (uniform)
+                // j comes before i (never true for j == i)
+                const bool before = (pj != myPerim[t]) ? pj > myPerim[t] : kj < myKey[t];
+                myRank[t] += before ? 1 : 0;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < PER; t++)
+            if (base + tid + NT * t < n) s_cenx[base + tid + NT * t] = __int_as_float(myRank[t]);
     }
     __syncthreads();
-#pragma unroll
-    for (int t = 0; t < PER; t++)
-        if (tid + NT * t < n) s_rank[tid + NT * t] = myRank[t];
+    for (int i = tid; i < n; i += NT) s_rank[i] = __float_as_int(s_cenx[i]);
     __syncthreads();
     for (int i = tid; i < n; i += NT) {
         const int r = s_rank[i];
@@ -227,49 +295,55 @@ __global__ __launch_bounds__(NT) void k_select(const QuadRec* __restrict__ quads
             const int i = i0 + slot;
             if (i >= n) break;  // (uniform per wavefront)
             const float cix = s_cenx[i], ciy = s_ceny[i];
-            uint32_t blocks = 0;
-            for (int b = (i + 1) >> 6; b < nBlocks; b++) {
-                const int j = 64 * b + lane;
-                bool nr = false;
-                if (j > i && j < n) {
-                    const float dx = s_cenx[j] - cix, dy = s_ceny[j] - ciy;
-                    const float lim = s_thr[j] * 1.01f + 1.f;
-                    nr = dx * dx + dy * dy <= lim * lim;
+            for (int w = 0; w < NBW; w++) {
+                unsigned long long blocks = 0;
+                for (int b = max((i + 1) >> 6, 64 * w); b < min(nBlocks, 64 * w + 64); b++) {
+                    const int j = 64 * b + lane;
+                    bool nr = false;
+                    if (j > i && j < n) {
+                        const float dx = s_cenx[j] - cix, dy = s_ceny[j] - ciy;
+                        const float lim = s_thr[j] * 1.01f + 1.f;
+                        nr = dx * dx + dy * dy <= lim * lim;
+                    }
+                    if (!__any(nr)) continue;
+                    bool close = false;
+                    if (nr) close = avg_distance(s_c[i], s_c[j]) < s_thr[j];
+                    const unsigned long long m = __ballot(close);
+                    if (m) {
+                        blocks |= 1ull << (b & 63);
+                        if (lane == 0) s_close[slot * NB + b] = m;
+                    }
                 }
-                if (!__any(nr)) continue;
-                bool close = false;
-                if (nr) close = avg_distance(s_c[i], s_c[j]) < s_thr[j];
-                const unsigned long long m = __ballot(close);
-                if (m) {
-                    blocks |= 1u << b;
-                    if (lane == 0) s_close[slot][b] = m;
-                }
+                if (lane == 0) s_closeBlocks[slot * NBW + w] = blocks;
             }
-            if (lane == 0) s_closeBlocks[slot] = blocks;
         }
         __syncthreads();
         if (tid == 0) {
             for (int slot = 0; slot < kGroupRound && i0 + slot < n; slot++) {
-                uint32_t blocks = s_closeBlocks[slot];
-                if (!blocks) continue;
+                unsigned long long any = 0;
+                for (int w = 0; w < NBW; w++) any |= s_closeBlocks[slot * NBW + w];
+                if (!any) continue;
                 const int i = i0 + slot;
                 int gi = s_gid[i];
-                while (blocks) {
-                    const int b = __ffs((int)blocks) - 1;
-                    blocks &= blocks - 1;
-                    unsigned long long m = s_close[slot][b];
-                    while (m) {
-                        const int jj = 64 * b + __ffsll((long long)m) - 1;
-                        m &= m - 1;
-                        s_isSel[jj] = 0;
-                        const int gj = s_gid[jj];
-                        if (gi < 0 && gj < 0) {
-                            gi = nG++;
-                            s_gid[jj] = (short)gi;
-                        } else if (gi > -1 && gj == -1) {
-                            s_gid[jj] = (short)gi;
-                        } else if (gj > -1 && gi == -1) {
-                            gi = gj;
+                for (int w = 0; w < NBW; w++) {
+                    unsigned long long blocks = s_closeBlocks[slot * NBW + w];
+                    while (blocks) {
+                        const int b = 64 * w + __ffsll((long long)blocks) - 1;
+                        blocks &= blocks - 1;
+                        unsigned long long m = s_close[slot * NB + b];
+                        while (m) {
+                            const int jj = 64 * b + __ffsll((long long)m) - 1;
+                            m &= m - 1;
+                            s_isSel[jj] = 0;
+                            const int gj = s_gid[jj];
+                            if (gi < 0 && gj < 0) {
+                                gi = nG++;
+                                s_gid[jj] = (short)gi;
+                            } else if (gi > -1 && gj == -1) {
+                                s_gid[jj] = (short)gi;
+                            } else if (gj > -1 && gi == -1) {
+                                gi = gj;
+                            }
                         }
                     }
                 }
@@ -335,14 +409,14 @@ __global__ __launch_bounds__(NT) void k_select(const QuadRec* __restrict__ quads
     if (GROUP_ONLY) {
         // what the identification has to look at: the selected candidates (pass 1), and the fall-backs of each with
         // their representative (pass 2, skipped for representatives that pass 1 identifies); any order
-        uint32_t* const list = idList + (size_t)f * kQuadCap;
+        uint32_t* const list = idList + (size_t)f * quadCap;
         for (int i = tid; i < n; i += NT) {
             st[i] = s_orig[i];
-            st[kQuadCap + i] = s_isSel[i];
-            st[2 * kQuadCap + i] = s_closeOf[i];
+            st[quadCap + i] = s_isSel[i];
+            st[2 * quadCap + i] = s_closeOf[i];
             if (s_isSel[i]) list[atomicAdd(&s_nList[0], 1)] = (uint32_t)(uint16_t)s_orig[i] | 0xFFFF0000u;
             const int c = s_closeOf[i];
-            if (c >= 0) list[kQuadCap - 1 - atomicAdd(&s_nList[1], 1)] = (uint32_t)(uint16_t)s_orig[i] | ((uint32_t)(uint16_t)s_orig[c] << 16);
+            if (c >= 0) list[quadCap - 1 - atomicAdd(&s_nList[1], 1)] = (uint32_t)(uint16_t)s_orig[i] | ((uint32_t)(uint16_t)s_orig[c] << 16);
         }
         __syncthreads();
         if (tid == 0) { idCount[2 * f] = s_nList[0]; idCount[2 * f + 1] = s_nList[1]; }
@@ -428,6 +502,7 @@ __global__ __launch_bounds__(NT) void k_select(const QuadRec* __restrict__ quads
 
     // ---- outputs: accepted markers and rejected candidates in the order of the selected list, 64 entries at a time
     //      (positions by ballot; every lane of the first wavefront writes its own entry) ----
+    const int markerOut = cfg.markerOut;
     int na = 0, nr = 0;  // uniform
     for (int v0 = 0; v0 < ns; v0 += 64) {
         const int v = v0 + lane;
@@ -438,26 +513,26 @@ __global__ __launch_bounds__(NT) void k_select(const QuadRec* __restrict__ quads
         const int myA = na + (int)__popcll(balA & below), myR = nr + (int)__popcll(balR & below);
         const int cntA = (int)__popcll(balA);
         // marker records: one reservation for the chunk's markers that fit the frame's output
-        const int fit = max(0, min(cntA, kMaxMarkerOut - na));
+        const int fit = max(0, min(cntA, markerOut - na));
         unsigned int slot0 = 0;
         if (fit > 0) {
             if (lane == 0) slot0 = atomicAdd(&ctr->nMarkers, (unsigned int)fit);
             slot0 = (unsigned int)__builtin_amdgcn_readfirstlane((int)slot0);
         }
         if (isAcc) {
-            if (myA < kMaxMarkerOut) {
+            if (myA < markerOut) {
                 const int u = s_use[v];
                 const int rot = s_rot[u];
                 // correctCornerPosition: std::rotate(begin, begin + 4 - rot, end)
-                float* o = outCorners + ((size_t)f * kMaxMarkerOut + myA) * 8;
-                float* o2 = rawCorners + ((size_t)f * kMaxMarkerOut + myA) * 8;
+                float* o = outCorners + ((size_t)f * markerOut + myA) * 8;
+                float* o2 = rawCorners + ((size_t)f * markerOut + myA) * 8;
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const int src = (k + 4 - rot) & 3;
                     o[2 * k] = o2[2 * k] = s_c[u][2 * src];
                     o[2 * k + 1] = o2[2 * k + 1] = s_c[u][2 * src + 1];
                 }
-                outIds[(size_t)f * kMaxMarkerOut + myA] = s_id[u];
+                outIds[(size_t)f * markerOut + myA] = s_id[u];
                 const unsigned int slot = slot0 + (unsigned int)(myA - na);
                 if (slot < markerCap) {
                     markers[slot].frame = (uint32_t)f;
@@ -468,8 +543,8 @@ __global__ __launch_bounds__(NT) void k_select(const QuadRec* __restrict__ quads
             } else {
                 atomicOr(&ctr->overflow, 32u);
             }
-        } else if (in && myR < kMaxRejectedOut) {
-            float* o = outRejected + ((size_t)f * kMaxRejectedOut + myR) * 8;
+        } else if (in && myR < quadCap) {
+            float* o = outRejected + ((size_t)f * quadCap + myR) * 8;
             const int u = s_sel[v];
 #pragma unroll
             for (int k = 0; k < 8; k++) o[k] = s_c[u][k];
@@ -478,26 +553,27 @@ __global__ __launch_bounds__(NT) void k_select(const QuadRec* __restrict__ quads
         nr += (int)__popcll(balR);
     }
     if (lane == 0) {
-        outCounts[f] = min(na, kMaxMarkerOut);
-        outRejCounts[f] = min(nr, kMaxRejectedOut);
+        outCounts[f] = min(na, markerOut);
+        if (na > markerOut) atomicMax(&ctr->needMarkers, (unsigned int)na);
+        outRejCounts[f] = min(nr, quadCap);
     }
 }
 
 // Results of a chunk in the caller's layout (camsync_detect_pnp_resident): ids [B,maxMarkers], corners
 // [B,maxMarkers,8], counts [B] clamped to the columns the caller gave.  Lane = one marker slot.
 __global__ __launch_bounds__(256) void k_export_markers(const int32_t* __restrict__ outIds, const float* __restrict__ outCorners,
-                                                        const int32_t* __restrict__ outCounts, int B, int maxMarkers,
+                                                        const int32_t* __restrict__ outCounts, int B, int maxMarkers, int markerOut,
                                                         int32_t* __restrict__ dIds, float* __restrict__ dCorners,
                                                         int32_t* __restrict__ dCounts) {
-    const int mm = min(maxMarkers, kMaxMarkerOut);
+    const int mm = min(maxMarkers, markerOut);
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= B * mm) return;
     const int f = i / mm, m = i - f * mm;
     const int n = min(max(outCounts[f], 0), mm);
     if (m == 0) dCounts[f] = n;
     if (m >= n) return;
-    dIds[(size_t)f * maxMarkers + m] = outIds[(size_t)f * kMaxMarkerOut + m];
-    const float4* src = reinterpret_cast<const float4*>(outCorners + ((size_t)f * kMaxMarkerOut + m) * 8);
+    dIds[(size_t)f * maxMarkers + m] = outIds[(size_t)f * markerOut + m];
+    const float4* src = reinterpret_cast<const float4*>(outCorners + ((size_t)f * markerOut + m) * 8);
     float* dst = dCorners + ((size_t)f * maxMarkers + m) * 8;  // the caller's buffer need not be 16-byte aligned
     const float4 a = src[0], b = src[1];
     dst[0] = a.x; dst[1] = a.y; dst[2] = a.z; dst[3] = a.w;
@@ -508,9 +584,9 @@ __global__ __launch_bounds__(256) void k_export_markers(const int32_t* __restric
 
 void launch_export_markers(const DetBuffers& b, int B, int maxMarkers, int32_t* dIds, float* dCorners, int32_t* dCounts,
                            hipStream_t st) {
-    const int mm = std::min(maxMarkers, kMaxMarkerOut);
+    const int mm = std::min(maxMarkers, b.markerOut);
     const unsigned blocks = (unsigned)(((size_t)B * mm + 255) / 256);
-    hipLaunchKernelGGL(k_export_markers, dim3(blocks), dim3(256), 0, st, b.outIds, b.outCorners, b.outCounts, B, maxMarkers,
+    hipLaunchKernelGGL(k_export_markers, dim3(blocks), dim3(256), 0, st, b.outIds, b.outCorners, b.outCounts, B, maxMarkers, b.markerOut,
                        dIds, dCorners, dCounts);
 }
 
@@ -520,17 +596,25 @@ template <int MODE>
 void launch_select_kernels(const DetCfg& c, const DetBuffers& b, int B, hipStream_t st) {
     // frames with up to 256 candidates: one wavefront per frame when there are frames enough to fill the chip that way,
     // four otherwise (latency of a small batch); frames with more candidates always get four
+    uint8_t* const none = nullptr;
     if (B >= 1024 && MODE != 1)  // (the grouping alone is faster with four even then: 0.23 -> 0.18 ms at 4096 frames)
         hipLaunchKernelGGL((k_select<256, 64, MODE>), dim3(B), dim3(64), 0, st, b.quads, b.qcount, c, b.outIds, b.outCorners, b.rawCorners,
-                           b.outCounts, b.outRejected, b.outRejCounts, b.markers, b.markerCap, b.counters, b.idList, b.idCount, b.selState);
+                           b.outCounts, b.outRejected, b.outRejCounts, b.markers, b.markerCap, b.counters, b.idList, b.idCount, b.selState, none);
     else
         hipLaunchKernelGGL((k_select<256, 256, MODE>), dim3(B), dim3(256), 0, st, b.quads, b.qcount, c, b.outIds, b.outCorners, b.rawCorners,
-                           b.outCounts, b.outRejected, b.outRejCounts, b.markers, b.markerCap, b.counters, b.idList, b.idCount, b.selState);
-    hipLaunchKernelGGL((k_select<kQuadCap, 256, MODE>), dim3(B), dim3(256), 0, st, b.quads, b.qcount, c, b.outIds, b.outCorners, b.rawCorners,
-                       b.outCounts, b.outRejected, b.outRejCounts, b.markers, b.markerCap, b.counters, b.idList, b.idCount, b.selState);
+                           b.outCounts, b.outRejected, b.outRejCounts, b.markers, b.markerCap, b.counters, b.idList, b.idCount, b.selState, none);
+    hipLaunchKernelGGL((k_select<kQuadLds, 256, MODE>), dim3(B), dim3(256), 0, st, b.quads, b.qcount, c, b.outIds, b.outCorners, b.rawCorners,
+                       b.outCounts, b.outRejected, b.outRejCounts, b.markers, b.markerCap, b.counters, b.idList, b.idCount, b.selState, none);
+    // (only once a frame has had more candidates than the LDS instances hold: the lists have grown, camsync_api.hip)
+    if (c.quadCap > kQuadLds && b.selWork)
+        hipLaunchKernelGGL((k_select<0, 256, MODE>), dim3(B), dim3(256), 0, st, b.quads, b.qcount, c, b.outIds, b.outCorners, b.rawCorners,
+                           b.outCounts, b.outRejected, b.outRejCounts, b.markers, b.markerCap, b.counters, b.idList, b.idCount, b.selState,
+                           b.selWork);
 }
 
 }  // namespace
+
+size_t sel_work_bytes(int quadCap) { return sel_work_layout(quadCap); }
 
 void launch_select(const DetCfg& c, const DetBuffers& b, int B, hipStream_t st) {
     if (b.identifyAll) launch_select_kernels<0>(c, b, B, st);

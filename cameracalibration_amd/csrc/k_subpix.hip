@@ -211,7 +211,7 @@ __global__ __launch_bounds__(64) void k_subpix(const uint8_t* __restrict__ gray,
     for (unsigned int job = blockIdx.x; job < nM * 4u; job += gridDim.x) {
         const MarkerRec mr = markers[job >> 2];
         const int corner = job & 3;
-        const float* mc = rawCorners + ((size_t)mr.frame * kMaxMarkerOut + mr.slot) * 8;
+        const float* mc = rawCorners + ((size_t)mr.frame * cfg.markerOut + mr.slot) * 8;
         const GraySrc src{gray + (size_t)mr.frame * H * W * grayC, grayC, (uint32_t)(H * W - 1)};
         // window from the marker's average module size (unrefined corners)
         float ms = 0.f;
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(64) void k_subpix(const uint8_t* __restrict__ gray,
         float cIx, cIy;
         refine_corner(src, W, H, mc[2 * corner], mc[2 * corner + 1], win, max_iters, eps, expTab, lane, s_buf, s_reg, cIx, cIy);
         if (lane == 0) {
-            float* dst = outCorners + ((size_t)mr.frame * kMaxMarkerOut + mr.slot) * 8;
+            float* dst = outCorners + ((size_t)mr.frame * cfg.markerOut + mr.slot) * 8;
             dst[2 * corner] = cIx;
             dst[2 * corner + 1] = cIy;
         }

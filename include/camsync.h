@@ -125,6 +125,12 @@ int camsync_detect_batch(camsync_ctx* ctx, const uint8_t* frames, int on_device,
                          int max_markers, int32_t* ids, float* corners, int32_t* counts,
                          int max_rejected, float* rejected, int32_t* rej_counts);
 
+/* The outputs of camsync_detect_batch / camsync_detect_pnp_batch / _frames hold at most max_markers (max_rejected)
+ * entries per frame and the counts are clamped to that.  camsync_last_extent reports the largest unclamped count of
+ * any frame of the last such call on this context, so that a caller who must not lose a marker (the reference's
+ * detectMarkers returns every one, aruco.py:256-264) can call again with wider outputs.  Either pointer may be NULL. */
+int camsync_last_extent(const camsync_ctx* ctx, int32_t* markers, int32_t* rejected);
+
 /* Intermediate results of the last chunk processed (parity tests and tuning, no counterpart in the
  * reference: OpenCV does not expose them).
  *   camsync_debug_counts   chunk-wide counters: [0] contour-start candidates, [1] contours kept by the
@@ -171,11 +177,14 @@ int camsync_debug_restore_capacity(camsync_ctx* ctx);
  * following calls identify every candidate, so that camsync_debug_quads reports an id for each. */
 int camsync_debug_identify_all(camsync_ctx* ctx, int on);
 
-/* The detection's scratch lists (start candidates, contour records, contour points, store / copy tasks, border seeds)
- * are sized at camsync_create; a chunk that overflows one is run again with that list doubled (the reference's
- * cv.aruco.detectMarkers has no such limits, aruco.py:256-264), and CAMSYNC_E_CAPACITY is left for a list that cannot
- * grow any more.  camsync_debug_shrink_lists replaces the lists by smaller ones (entries; 0 = leave) so that tests can
- * make that happen; camsync_debug_regrown counts the doublings since camsync_create. */
+/* The detection's scratch lists (start candidates, contour records, contour points, store / copy tasks, border seeds;
+ * per frame: 1024 quad candidates and 64 accepted markers) are sized at camsync_create; a chunk that overflows one is
+ * run again with that list grown (doubled; the per-frame lists to what the fullest frame needs) -- the reference's
+ * cv.aruco.detectMarkers has no such limits, aruco.py:256-264 -- and CAMSYNC_E_CAPACITY is left for a list that cannot
+ * grow any more (2^31 entries, 32768 quad candidates in one frame, or no device memory).  Frames with more than 1024
+ * quad candidates take a slower selection kernel (working set in global memory instead of LDS).
+ * camsync_debug_shrink_lists replaces the lists by smaller ones (entries; 0 = leave) so that tests can make that
+ * happen; camsync_debug_regrown counts the growths since camsync_create. */
 int camsync_debug_shrink_lists(camsync_ctx* ctx, unsigned int starts, unsigned int contours, unsigned int points,
                                unsigned int tasks, unsigned int seeds);
 int camsync_debug_regrown(const camsync_ctx* ctx);

@@ -109,7 +109,9 @@ def detect(img, params=None, max_markers=256, max_rejected=1024):
     rej = np.zeros((max_rejected, 4, 2), np.float32); nrej = C.c_int32(0)
     n = lib().orc_detect(_p(img), h, w, ch, C.byref(p), _p(codes), len(codes), _p(ids), _p(cor), max_markers,
                          _p(rej), max_rejected, C.byref(nrej))
-    assert 0 <= n <= max_markers
+    assert n >= 0
+    if n > max_markers or nrej.value > max_rejected:  # (the oracle has no limits: again with room for everything)
+        return detect(img, params, max(n, max_markers), max(nrej.value, max_rejected))
     return ids[:n].copy(), cor[:n].copy(), rej[:min(nrej.value, max_rejected)].copy()
 
 
