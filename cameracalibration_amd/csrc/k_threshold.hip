@@ -6,19 +6,24 @@
 // 512-column strip of one frame top to bottom; 16 columns on each side are
 // halo, 480 produce output (1920 = 4 strips).  Each lane owns 8 adjacent
 // columns.  Per row the lane reads its 24 BGR bytes once (coalesced), converts
-// to luma with two byte dot products, writes the gray row, keeps the last
-// 2*rmax+2 gray rows (the newest rmax+1 in registers, the older rmax+1 in an LDS
-// ring: LDS per wave decides the occupancy, and this kernel lives on occupancy)
-// and maintains the vertical running sums of the three windows in registers as
-// packed 16-bit pairs.  The vertical sums
-// are exchanged through LDS and slid horizontally, so every input byte is
-// fetched from HBM once (plus the strip halos) and the three threshold images
-// leave as bit planes (one bit per pixel and scale).
+// to luma with two byte dot products, keeps the last 2*rmax+2 gray rows (the
+// newest rmax+4 in registers, the older rmax+1 in an LDS ring) and maintains
+// the vertical running sums of the three windows in registers as packed 16-bit
+// pairs.  The vertical sums are exchanged through LDS and slid horizontally, so
+// every input byte is fetched from HBM once (plus the strip halos) and the
+// three threshold images leave as bit planes (one bit per pixel and scale).
+// The gray image itself is written only when a caller asks for it
+// (camsync_gray_threshold, detector parameters the fused kernel does not
+// cover): the pipeline's later stages convert the few gray values they need
+// from the input frame (internal.h, GraySrc).
 //
-// What bounds it (measured by taking parts out, profiles/r01_notes.md): memory, and within memory the writes.
-// With all arithmetic removed the kernel takes as long as with it; the 1.4 B/px it writes cost as much time as
-// the 3.4 B/px it reads.  Hence the strips of one band are placed on one XCD (the cache lines that two strips
-// write parts of, and the halo columns both read, meet in one L2) and the plane bits leave in 64-byte pieces.
+// What bounds it: vector instruction issue.  While it still wrote the gray image it was bound by memory, and within
+// memory by the writes (round 1, profiles/r01_notes.md); without the gray image it moves 3.08 B/px in and 0.38 B/px out
+// (counters, profiles/r03_pmc_k_gray_thresh3.json: 3.3 TB/s, a memory floor of ~7 ms for 4096 1080p frames), and the
+// ~243 vector instructions per row of 8 pixels a lane (37 gray conversion, 48 vertical sums, 69 horizontal sums,
+// 56 thresholds, the rest staging and addressing) keep the vector unit busy in every cycle of its 8.9 ms at three
+// waves per SIMD (146 registers, 12 KB of LDS per wave).  The strips of one band are placed on one XCD (the halo
+// columns two strips both read meet in one L2) and the plane bits leave in 64-byte pieces.
 //
 // Integer-exact: luma = (3735 B + 19235 G + 9798 R + 2^14) >> 15;
 // out_s = 1  <=>  round(sum/k^2) >= src + idelta  <=>  2 sum >= (2(src+idelta)-1) k^2
