@@ -21,9 +21,9 @@
  *       (reference camera_sync/test_aruco.py:329-359)                              PINNED
  *   P3  Rodrigues both ways (reference camera_sync/test_referential.py)            PINNED
  *   P4  dictionary ids 10..15, 20..47 from the reference's printable sheets        PINNED
- *   P5  pics/calib/*.jpg -> calibration/robot_640-480_500.npz (chessboard corners,
+ *   P5  pics/calib/ *.jpg -> calibration/robot_640-480_500.npz (chessboard corners,
  *       cornerSubPix, calibrateCamera end to end)                                  PINNED
- *   P6  pics/blender/calib/*.png -> calibration/blender_1920-1080_0.npz            PINNED
+ *   P6  pics/blender/calib/ *.png -> calibration/blender_1920-1080_0.npz            PINNED
  *   P7  dictionary ids 0..3 from pics/robot_calib (the v1 sheet's small markers)   PINNED
  *   IPPE_SQUARE numerics, undistort pixels, YUYV conversion, the `rejected` list,
  *   output order, dictionary ids 4..9, 16..19, 48, 49:                            parity unpinned
@@ -31,6 +31,7 @@
 #ifndef CAMSYNC_ORACLE_H
 #define CAMSYNC_ORACLE_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -165,6 +166,14 @@ int orc_chess_candidates(const uint8_t* gray, int H, int W, int scale, int max_c
 /* Frame ingest (reference camera_sync/camera.py:104-118, 150-154: VideoCapture.read()): packed YUYV 4:2:2 as a UVC
  * camera delivers it -> BGR, as cv.cvtColor(COLOR_YUV2BGR_YUYV) (oracle/ingest.cpp).  PARITY UNPINNED. */
 int orc_yuyv_to_bgr(const uint8_t* yuyv, int H, int W, uint8_t* bgr);
+
+/* Frame ingest, compressed (same call sites: VideoCapture.read() on an MJPG camera; cv.imread of the reference's
+ * pics/ *.jpg): baseline JPEG -> BGR as libjpeg-turbo decodes it with its defaults (oracle/jpeg.cpp).  Pinned against
+ * Pillow's libjpeg-turbo on the reference's 21 JPEG photos, not against a reference-held output.
+ * orc_jpeg_info: size of the image; orc_jpeg_decode: bgr u8 [H,W,3].  0, or < 0: -1 not a JPEG / truncated headers,
+ * -2 outside the scope (progressive, arithmetic, 4 components, other samplings), -3 corrupt entropy data, -4 bgr too small. */
+int orc_jpeg_info(const uint8_t* data, size_t n, int32_t* height, int32_t* width, int32_t* components);
+int orc_jpeg_decode(const uint8_t* data, size_t n, uint8_t* bgr, size_t cap);
 
 #ifdef __cplusplus
 }

@@ -278,3 +278,17 @@ def yuyv_to_bgr(yuyv):
     if rc:
         raise ValueError("orc_yuyv_to_bgr: bad arguments")
     return out
+
+
+def jpeg_decode(data):
+    """One JPEG file / MJPEG frame (bytes) -> BGR [H,W,3] as libjpeg-turbo decodes it (oracle/jpeg.cpp)."""
+    buf = np.frombuffer(bytes(data), np.uint8)
+    h = C.c_int32(0); w = C.c_int32(0); nc = C.c_int32(0)
+    rc = lib().orc_jpeg_info(_p(buf), C.c_size_t(len(buf)), C.byref(h), C.byref(w), C.byref(nc))
+    if rc:
+        raise ValueError("orc_jpeg_info: %d" % rc)
+    out = np.empty((h.value, w.value, 3), np.uint8)
+    rc = lib().orc_jpeg_decode(_p(buf), C.c_size_t(len(buf)), _p(out), C.c_size_t(out.size))
+    if rc:
+        raise ValueError("orc_jpeg_decode: %d" % rc)
+    return out

@@ -1,0 +1,104 @@
+"""Compressed frame ingest (baseline JPEG / MJPEG frames).
+
+CPU part: the oracle (oracle/jpeg.cpp, a restatement of libjpeg-turbo's default decoding path, which is what
+cv.VideoCapture.read() on an MJPG camera and cv.imread give the reference, camera.py:98-118, 150-154) against Pillow,
+which decodes with libjpeg-turbo too: bit for bit on the reference's own 21 JPEG photos and on re-encodings that cover
+the samplings, odd sizes, optimised tables, restart intervals and MJPEG frames without Huffman tables.  The reference
+holds the JPEG files but no decoded pixels, so this pins the oracle to libjpeg-turbo, not to a reference-held output.
+
+GPU part: camsync_decode_jpeg_batch against the oracle, bit for bit."""
+import io
+import os
+
+import numpy as np
+import pytest
+from PIL import Image
+
+from tests import _data, _oracle as orc
+
+
+def _pil_bgr(data):
+    rgb = np.array(Image.open(io.BytesIO(data)).convert("RGB"))
+    return np.ascontiguousarray(rgb[:, :, ::-1])
+
+
+def _reference_jpegs():
+    out = []
+    for d in ("calib", "poses", "robot_calib"):
+        folder = os.path.join(_data.GOLDEN, d)
+        out += [os.path.join(folder, f) for f in sorted(os.listdir(folder)) if f.endswith(".jpg")]
+    return out
+
+
+def _scene(h, w, seed):
+    """Smooth gradients, sharp edges and noise: exercises long zero runs, large DC steps and every coefficient."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = np.stack([(xx * 255 // max(w - 1, 1)), (yy * 255 // max(h - 1, 1)), ((xx + yy) * 3) % 256], -1).astype(np.int32)
+    img[h // 4:h // 2, w // 4:w // 2] = (250, 10, 10)
+    img[h // 2:, : w // 3] = rng.integers(0, 256, (h - h // 2, w // 3, 3))
+    img += rng.integers(-8, 9, img.shape)
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def _encode(img, **kw):
+    b = io.BytesIO()
+    Image.fromarray(img).save(b, "JPEG", **kw)
+    return b.getvalue()
+
+
+def strip_dht(data):
+    """The frame as an MJPEG camera sends it: without its DHT segments (the decoder then uses the Annex K tables, which
+    are what Pillow writes unless asked to optimise)."""
+    out = bytearray(data[:2])
+    i = 2
+    while data[i + 1] != 0xDA:
+        L = (data[i + 2] << 8) | data[i + 3]
+        if data[i + 1] != 0xC4:
+            out += data[i:i + 2 + L]
+        i += 2 + L
+    return bytes(out + data[i:])
+
+
+VARIANTS = [
+    dict(quality=90, subsampling=0), dict(quality=75, subsampling=1), dict(quality=60, subsampling=2),
+    dict(quality=95, subsampling=2, optimize=True), dict(quality=30, subsampling=1, restart_marker_blocks=3),
+    dict(quality=85, subsampling=2, restart_marker_rows=1), dict(quality=100, subsampling=0),
+    dict(quality=5, subsampling=2),
+]
+
+
+def test_oracle_equals_libjpeg_turbo_on_the_reference_photos():
+    files = _reference_jpegs()
+    assert len(files) == 21
+    for f in files:
+        data = open(f, "rb").read()
+        assert np.array_equal(orc.jpeg_decode(data), _pil_bgr(data)), f
+
+
+@pytest.mark.parametrize("hw", [(48, 64), (50, 70), (33, 47), (480, 640), (8, 8), (17, 250)])
+def test_oracle_equals_libjpeg_turbo_on_encodings(hw):
+    img = _scene(hw[0], hw[1], hw[0] * 1000 + hw[1])
+    for kw in VARIANTS:
+        data = _encode(img, **kw)
+        assert np.array_equal(orc.jpeg_decode(data), _pil_bgr(data)), kw
+    gray = _encode(img[..., 0], quality=80)
+    assert np.array_equal(orc.jpeg_decode(gray), _pil_bgr(gray))
+
+
+def test_mjpeg_frames_without_huffman_tables():
+    img = _scene(96, 128, 7)
+    data = _encode(img, quality=80, subsampling=1)
+    bare = strip_dht(data)
+    assert len(bare) < len(data) and b"\xff\xc4" not in bare[:600]
+    assert np.array_equal(orc.jpeg_decode(bare), _pil_bgr(data))
+
+
+def test_what_the_decoder_does_not_take():
+    img = _scene(48, 64, 3)
+    with pytest.raises(ValueError):
+        orc.jpeg_decode(_encode(img, progressive=True))
+    with pytest.raises(ValueError):
+        orc.jpeg_decode(b"\x89PNG....")
+    with pytest.raises(ValueError):
+        orc.jpeg_decode(_encode(img, quality=80)[:200])
