@@ -121,6 +121,8 @@ def load_library() -> C.CDLL:
         lib.camsync_optimal_new_camera_matrix.argtypes = [vp, vp, i32, i32, i32, dbl, i32, i32, vp, vp]
         lib.camsync_undistort_batch.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp]
         lib.camsync_ingest_yuyv.argtypes = [vp, vp, i32, i32, i32, i32, vp, i32]
+        lib.camsync_jpeg_info.argtypes = [vp, C.c_size_t, vp, vp, vp]
+        lib.camsync_decode_jpeg_batch.argtypes = [vp, vp, vp, i32, i32, i32, vp, i32]
         lib.camsync_calibrate.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp]
         lib.camsync_calibrate_dist.argtypes = [vp, vp, vp, i32, i32, C.c_int64, i32, i32, i32, i32, ALLREDUCE_FN, vp, vp,
                                                vp, vp, vp, vp, vp, vp]
@@ -162,6 +164,17 @@ def _cam(K, dist, B):
             raise ValueError("thin-prism / tilt distortion terms are not supported")
         d = np.ascontiguousarray(d[:, :8])
     return K, d, per_frame
+
+
+def jpeg_info(data):
+    """(height, width, components) of a JPEG file / MJPEG frame, from its header (host only)."""
+    buf = data if isinstance(data, np.ndarray) else np.frombuffer(bytes(data), np.uint8)
+    h = C.c_int32(0)
+    w = C.c_int32(0)
+    n = C.c_int32(0)
+    if load_library().camsync_jpeg_info(_ptr(buf), C.c_size_t(buf.size), C.byref(h), C.byref(w), C.byref(n)):
+        raise ValueError("not a JPEG, or its headers are damaged")
+    return h.value, w.value, n.value
 
 
 class PinnedFrames:
@@ -511,6 +524,24 @@ class Context:
         out = np.empty((B, H, W, 3), np.uint8)
         self._check(self._lib.camsync_ingest_yuyv(self._h, in_ptr, in_dev, B, H, W, _ptr(out), 0))
         return out[0] if one else out
+
+    def decode_jpeg(self, jpegs, d_bgr_ptr=None):
+        """Baseline JPEG files / MJPEG frames (a sequence of bytes objects, all of one image size) -> BGR frames as
+        cv.imread / cv.VideoCapture.read() decode them.  Returns a host array [B,H,W,3], or with d_bgr_ptr (raw device
+        pointer to B*H*W*3 bytes) leaves the frames on the GPU and returns their shape."""
+        bufs = [np.frombuffer(bytes(j), np.uint8) for j in jpegs]
+        B = len(bufs)
+        if not B:
+            raise ValueError("no frames")
+        H, W, _ = jpeg_info(bufs[0])
+        ptrs = (C.c_void_p * B)(*[b.ctypes.data for b in bufs])
+        sizes = (C.c_size_t * B)(*[b.size for b in bufs])
+        if d_bgr_ptr is not None:
+            self._check(self._lib.camsync_decode_jpeg_batch(self._h, ptrs, sizes, B, H, W, C.c_void_p(d_bgr_ptr), 1))
+            return (B, H, W, 3)
+        out = np.empty((B, H, W, 3), np.uint8)
+        self._check(self._lib.camsync_decode_jpeg_batch(self._h, ptrs, sizes, B, H, W, _ptr(out), 0))
+        return out
 
     # -- undistortion --------------------------------------------------
     def undistort(self, frames, K, dist, new_K=None):

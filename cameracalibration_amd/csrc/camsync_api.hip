@@ -64,6 +64,7 @@ struct camsync_ctx {
     int lastB = 0, lastH = 0, lastW = 0;
     int hostMarkerOut = 0, hostQuadCap = 0;  // strides the pinned host buffers h_ids / h_corners and h_rej were sized for
     int lastMarkers = 0, lastRejected = 0;   // most markers / rejected candidates a frame of the last detection call had
+    JpegState* jpeg = nullptr;  // compressed frame ingest (created on first use)
     int regrown = 0;  // times a scratch list was doubled after an overflow (grow_lists)
     // the last camsync_detect_pnp_batch / _frames call, when it was one chunk: its detections and camera poses are still
     // on the device for camsync_fuse_moving_markers (poseFrames = 0: nothing to fuse from)
@@ -743,6 +744,7 @@ void camsync_destroy(camsync_ctx* c) {
                     c->d_calWork, c->d_focalRows, c->d_calOk, c->d_calK, c->d_calNpts};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    jpeg_destroy(c->jpeg);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     void* hostPtrs[] = {c->h_ids, c->h_corners, c->h_counts, c->h_rejCounts, c->h_rej};
     for (void* p : hostPtrs)
@@ -1621,6 +1623,27 @@ int camsync_ingest_yuyv(camsync_ctx* c, const uint8_t* yuyv, int in_on_device, i
         if (!out_on_device) HIPCHK(c, hipMemcpyAsync(dst, c->d_uout, (size_t)nb * px * 3, hipMemcpyDeviceToHost, c->stream));
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return CAMSYNC_OK;
+}
+
+int camsync_jpeg_info(const uint8_t* data, size_t n, int32_t* height, int32_t* width, int32_t* components) {
+    return jpeg_info(data, n, height, width, components);
+}
+
+int camsync_decode_jpeg_batch(camsync_ctx* c, const uint8_t* const* jpegs, const size_t* sizes, int B, int H, int W, uint8_t* bgr,
+                              int out_on_device) {
+    if (!c) return CAMSYNC_E_ARG;
+    if (!jpegs || !sizes || !bgr || B <= 0) return fail(c, CAMSYNC_E_ARG, "jpegs / sizes / bgr is NULL or batch <= 0");
+    if (H < 8 || W < 8 || H > c->maxH || W > c->maxW)
+        return fail(c, CAMSYNC_E_ARG, "frame %dx%d outside the context's range (8..%d x 8..%d)", H, W, c->maxH, c->maxW);
+    if (out_on_device && ((uintptr_t)bgr % 4)) return fail(c, CAMSYNC_E_ARG, "the device output must be 4-byte aligned");
+    for (int i = 0; i < B; i++)
+        if (!jpegs[i] || sizes[i] < 4) return fail(c, CAMSYNC_E_ARG, "frame %d is NULL or shorter than a JPEG header", i);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->jpeg) c->jpeg = jpeg_create();
+    std::string err;
+    const int rc = jpeg_decode_batch(c->jpeg, c->stream, jpegs, sizes, B, H, W, bgr, out_on_device, err);
+    if (rc) return fail(c, rc, "camsync_decode_jpeg_batch: %s", err.c_str());
     return CAMSYNC_OK;
 }
 

@@ -6,6 +6,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <stdint.h>
+
+#include <string>
 #include "../../include/camsync.h"
 
 namespace camsync {
@@ -315,6 +317,14 @@ void optimal_new_camera_matrix(const double* K, const double* k8, int W, int H, 
 bool undistort_camera_ok(const double* newK);
 void launch_undistort_map(const double* K, const double* newK, const double* k8, int H, int W, uint2* map, hipStream_t st);
 void launch_remap(const uint8_t* src, const uint2* map, uint8_t* dst, int B, int H, int W, int C, hipStream_t st);
+
+// compressed frame ingest (k_jpeg.hip)
+struct JpegState;
+JpegState* jpeg_create();
+void jpeg_destroy(JpegState* s);
+int jpeg_info(const uint8_t* data, size_t n, int32_t* height, int32_t* width, int32_t* components);
+int jpeg_decode_batch(JpegState* s, hipStream_t st, const uint8_t* const* jpegs, const size_t* sizes, int B, int H, int W,
+                      uint8_t* out, int outOnDevice, std::string& err);
 
 // calibration
 struct CalibState {

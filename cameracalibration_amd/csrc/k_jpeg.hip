@@ -1,0 +1,768 @@
+// k_jpeg.hip — compressed frame ingest: baseline JPEG / MJPEG frames -> BGR frames on the device, as
+// cv.VideoCapture(...).read() on a camera that delivers MJPG and cv.imread of the reference's stored photos give
+// them to the reference (camera_sync/camera.py:98-118, 150-154; both end in libjpeg-turbo with its defaults:
+// accurate integer IDCT, triangle-filter chroma upsampling, 16-bit fixed-point YCbCr -> RGB).
+//
+// Three kernels per batch:
+//   k_jpeg_huff   entropy decoding (ITU T.81 Annex F).  A frame's Huffman stream is sequential, so the parallelism is
+//                 the batch: one lane per frame, the 64 frames of a workgroup share their Huffman tables in LDS (the
+//                 host groups frames by table set: the frames of one camera all use one).  Every lane decodes one
+//                 symbol per iteration whatever block or coefficient it is at (a flat state machine: no lane waits
+//                 for another's block to end) and stores the coefficient straight into the frame's coefficient
+//                 planes, which are all zero between calls.
+//   k_jpeg_idct   dequantisation + inverse DCT (jidctint.c's two passes, 32-bit) of every block: eight lanes per block,
+//                 a row of coefficients each (coalesced 16-byte loads), transposed through LDS for the column pass;
+//                 writes the component planes and puts the zeros back into the coefficient planes.
+//   k_jpeg_color  chroma upsampling (h2v1 / h2v2 triangle filters, or none) + colour conversion + BGR packing, four
+//                 pixels per lane.
+// Bound: the Huffman kernel by the latency of one lane's dependent chain (≈ 70 instructions per symbol), the other two
+// by HBM (128 B + 128 B + 64 B per block; 1.5-3 B + 3 B per pixel).
+//
+// Scope (the host parser refuses the rest with CAMSYNC_E_ARG): SOF0 / SOF1, 8-bit, one interleaved scan, 1 or 3
+// components (Y / YCbCr), luma sampling 1x1, 2x1 or 2x2 with 1x1 chroma, restart intervals, frames without DHT
+// segments (the Annex K tables).  Results equal the CPU restatement under tests/ bit for bit (tests/test_jpeg.py).
+#include "internal.h"
+
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace camsync {
+
+namespace {
+
+struct JpegDesc {         // one frame
+    uint32_t dataOff;     // its entropy-coded bytes in the batch's byte buffer
+    uint32_t dataLen;
+    uint16_t restart;     // restart interval in MCUs, 0 = none
+    uint16_t mcux, mcuy;
+    uint8_t nc, hmax, vmax;
+    uint8_t tq[3], td[3], ta[3];  // quantisation table; DC / AC table as a slot (0..2) of the workgroup's table set
+    uint8_t pad;
+};
+
+constexpr int kHuffTableBytes = 1024;  // look[256] u16 | maxcode[18] i32 | valoff[17] i32 | huffval[256] u8
+constexpr int kHuffSetTables = 6;      // DC slots 0..2, AC slots 0..2
+constexpr int kOffMaxcode = 512, kOffValoff = 512 + 72, kOffHuffval = 512 + 72 + 68;
+
+__constant__ uint8_t c_zigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                                     41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                                     30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+const uint8_t h_zigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                              41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                              30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+__device__ __forceinline__ void wave_lds_order() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---- entropy decoding ------------------------------------------------------------------------------------------------
+// groups: [nGroups][65] = table set, then 64 frame indices (-1 = none).  status[f]: 0 ok, 1 corrupt entropy data.
+__global__ __launch_bounds__(64) void k_jpeg_huff(const uint8_t* __restrict__ bytes, const JpegDesc* __restrict__ desc,
+                                                  const int32_t* __restrict__ groups, const uint8_t* __restrict__ tableSets,
+                                                  int16_t* __restrict__ coef, uint32_t frameBlocks, int32_t* __restrict__ status) {
+    __shared__ __align__(16) uint8_t s_tab[kHuffSetTables * kHuffTableBytes];
+    __shared__ uint8_t s_zz[64];
+    const int lane = threadIdx.x;
+    const int32_t* grp = groups + (size_t)blockIdx.x * 65;
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(tableSets + (size_t)grp[0] * kHuffSetTables * kHuffTableBytes);
+        uint4* dst = reinterpret_cast<uint4*>(s_tab);
+        for (int i = lane; i < kHuffSetTables * kHuffTableBytes / 16; i += 64) dst[i] = src[i];
+        s_zz[lane] = c_zigzag[lane];
+    }
+    __syncthreads();
+    const int f = grp[1 + lane];
+    if (f < 0) return;
+    const JpegDesc d = desc[f];
+    const uint8_t* const p = bytes + d.dataOff;
+    const uint32_t limit = d.dataLen;
+    int16_t* const fcoef = coef + (size_t)f * frameBlocks * 64;
+    const int nc = d.nc;
+    // blocks per row of each component's plane, and the plane's first block
+    const uint32_t bw0 = (uint32_t)d.mcux * d.hmax, n0 = bw0 * ((uint32_t)d.mcuy * d.vmax), n1 = (uint32_t)d.mcux * d.mcuy;
+
+    uint64_t acc = 0;   // unread bits, left-aligned
+    int nb = 0;         // how many of them are valid
+    uint32_t ptr = 0;   // next byte to read
+    bool atMarker = false;
+    int pred0 = 0, pred1 = 0, pred2 = 0;
+    int c = 0, bx = 0, by = 0, k = 0;
+    uint32_t mx = 0, my = 0;
+    int toRestart = d.restart, nextRst = 0;
+    bool bad = false;
+    uint32_t block = 0;  // the current block's first coefficient
+    bool active = true;
+
+    while (active) {
+        // ---- at least 33 valid bits: a code (<= 16 bits) and its value (<= 16 bits) ----
+        if (nb <= 32) {
+            if (atMarker) {
+                nb = 64;  // (zeros, as jdhuff.c feeds after a marker)
+            } else {
+                uint32_t w = 0;
+                bool fast = ptr + 4 <= limit;
+                if (fast) {
+                    __builtin_memcpy(&w, p + ptr, 4);
+                    const uint32_t t = ~w;  // a zero byte of t is an 0xFF byte of w
+                    fast = ((t - 0x01010101u) & ~t & 0x80808080u) == 0;
+                }
+                if (fast) {
+                    acc |= (uint64_t)__builtin_bswap32(w) << (32 - nb);
+                    nb += 32;
+                    ptr += 4;
+                } else {
+                    while (nb <= 56) {
+                        if (ptr >= limit) { atMarker = true; break; }
+                        uint32_t b = p[ptr];
+                        if (b == 0xFF) {
+                            const uint32_t nx = ptr + 1 < limit ? p[ptr + 1] : 0xD9u;
+                            if (nx != 0) { atMarker = true; break; }
+                            ptr += 2;  // a stuffed zero
+                        } else {
+                            ptr++;
+                        }
+                        acc |= (uint64_t)b << (56 - nb);
+                        nb += 8;
+                    }
+                    if (atMarker) nb = 64;
+                }
+            }
+        }
+        // ---- one symbol ----
+        const int slot = k == 0 ? (c == 0 ? d.td[0] : c == 1 ? d.td[1] : d.td[2]) : 3 + (c == 0 ? d.ta[0] : c == 1 ? d.ta[1] : d.ta[2]);
+        const uint8_t* const T = s_tab + slot * kHuffTableBytes;
+        const uint32_t e = reinterpret_cast<const uint16_t*>(T)[(uint32_t)(acc >> 56)];
+        int l, sym;
+        if (e) {
+            l = (int)(e >> 8);
+            sym = (int)(e & 255u);
+        } else {
+            const int32_t* maxcode = reinterpret_cast<const int32_t*>(T + kOffMaxcode);
+            l = 9;
+            while (l <= 16 && (int32_t)(acc >> (64 - l)) > maxcode[l]) l++;
+            if (l > 16) {
+                bad = true;
+                l = 16;
+                sym = 0;
+            } else {
+                const int32_t* valoff = reinterpret_cast<const int32_t*>(T + kOffValoff);
+                sym = T[kOffHuffval + (((int32_t)(acc >> (64 - l)) + valoff[l]) & 255)];
+            }
+        }
+        acc <<= l;
+        nb -= l;
+        const int s = k == 0 ? sym : (sym & 15);
+        int val = 0;
+        if (s) {
+            const int sl = min(s, 16);
+            const int r = (int)(acc >> (64 - sl));
+            acc <<= sl;
+            nb -= sl;
+            val = r < (1 << (sl - 1)) ? r - (1 << sl) + 1 : r;
+        }
+        if (k == 0) {
+            if (sym > 16) bad = true;
+            int pr = c == 0 ? pred0 : c == 1 ? pred1 : pred2;
+            pr += val;
+            if (c == 0) pred0 = pr; else if (c == 1) pred1 = pr; else pred2 = pr;
+            // the block this DC coefficient starts
+            const uint32_t bwc = c == 0 ? bw0 : (uint32_t)d.mcux;
+            const uint32_t row = c == 0 ? my * d.vmax + (uint32_t)by : my, col = c == 0 ? mx * d.hmax + (uint32_t)bx : mx;
+            block = ((c == 0 ? 0u : c == 1 ? n0 : n0 + n1) + row * bwc + col) * 64u;
+            fcoef[block] = (int16_t)pr;
+            k = 1;
+        } else {
+            const int r = sym >> 4;
+            if (s) {
+                k += r;
+                if (k > 63) { bad = true; k = 64; }
+                else { fcoef[block + s_zz[k]] = (int16_t)val; k++; }
+            } else {
+                k = r == 15 ? k + 16 : 64;
+            }
+        }
+        if (bad) {
+            status[f] = 1;
+            active = false;
+        } else if (k >= 64) {
+            // ---- next block, MCU, restart interval ----
+            k = 0;
+            const int hc = c == 0 ? d.hmax : 1, vc = c == 0 ? d.vmax : 1;
+            if (++bx == hc) {
+                bx = 0;
+                if (++by == vc) {
+                    by = 0;
+                    if (++c == nc) {
+                        c = 0;
+                        if (++mx == d.mcux) { mx = 0; my++; }
+                        if (my == d.mcuy) {
+                            active = false;
+                        } else if (d.restart && --toRestart == 0) {
+                            // the bits left are the padding of the interval's last byte; the marker follows (after fill bytes)
+                            acc = 0;
+                            nb = 0;
+                            while (ptr + 1 < limit && p[ptr] == 0xFF && p[ptr + 1] == 0xFF) ptr++;
+                            if (ptr + 1 < limit && p[ptr] == 0xFF && p[ptr + 1] == (uint32_t)(0xD0 + nextRst)) {
+                                ptr += 2;
+                                atMarker = false;
+                                nextRst = (nextRst + 1) & 7;
+                                pred0 = pred1 = pred2 = 0;
+                                toRestart = d.restart;
+                            } else {
+                                status[f] = 1;
+                                active = false;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---- dequantisation + inverse DCT -----------------------------------------------------------------------------------
+// jidctint.c, jpeg_idct_islow: CONST_BITS 13, PASS1_BITS 2; one pass over eight values, arithmetic modulo 2^32
+__device__ __forceinline__ int32_t jmul(int32_t a, int32_t b) { return (int32_t)((uint32_t)a * (uint32_t)b); }
+__device__ __forceinline__ int32_t jdescale(int32_t x, int n) { return (int32_t)((uint32_t)x + (1u << (n - 1))) >> n; }
+template <int SHIFT>
+__device__ __forceinline__ void idct_1d(const int32_t* in, int32_t* out) {
+    constexpr int32_t F_0_298 = 2446, F_0_390 = 3196, F_0_541 = 4433, F_0_765 = 6270, F_0_899 = 7373, F_1_175 = 9633,
+                      F_1_501 = 12299, F_1_847 = 15137, F_1_961 = 16069, F_2_053 = 16819, F_2_562 = 20995, F_3_072 = 25172;
+    uint32_t z2 = (uint32_t)in[2], z3 = (uint32_t)in[6];
+    uint32_t z1 = (uint32_t)jmul((int32_t)(z2 + z3), F_0_541);
+    uint32_t tmp2 = z1 + (uint32_t)jmul((int32_t)z3, -F_1_847);
+    uint32_t tmp3 = z1 + (uint32_t)jmul((int32_t)z2, F_0_765);
+    uint32_t tmp0 = ((uint32_t)in[0] + (uint32_t)in[4]) << 13;
+    uint32_t tmp1 = ((uint32_t)in[0] - (uint32_t)in[4]) << 13;
+    const uint32_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+    tmp0 = (uint32_t)in[7]; tmp1 = (uint32_t)in[5]; tmp2 = (uint32_t)in[3]; tmp3 = (uint32_t)in[1];
+    z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2;
+    uint32_t z4 = tmp1 + tmp3;
+    const uint32_t z5 = (uint32_t)jmul((int32_t)(z3 + z4), F_1_175);
+    tmp0 = (uint32_t)jmul((int32_t)tmp0, F_0_298); tmp1 = (uint32_t)jmul((int32_t)tmp1, F_2_053);
+    tmp2 = (uint32_t)jmul((int32_t)tmp2, F_3_072); tmp3 = (uint32_t)jmul((int32_t)tmp3, F_1_501);
+    z1 = (uint32_t)jmul((int32_t)z1, -F_0_899); z2 = (uint32_t)jmul((int32_t)z2, -F_2_562);
+    z3 = (uint32_t)jmul((int32_t)z3, -F_1_961); z4 = (uint32_t)jmul((int32_t)z4, -F_0_390);
+    z3 += z5; z4 += z5;
+    tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
+    out[0] = jdescale((int32_t)(tmp10 + tmp3), SHIFT); out[7] = jdescale((int32_t)(tmp10 - tmp3), SHIFT);
+    out[1] = jdescale((int32_t)(tmp11 + tmp2), SHIFT); out[6] = jdescale((int32_t)(tmp11 - tmp2), SHIFT);
+    out[2] = jdescale((int32_t)(tmp12 + tmp1), SHIFT); out[5] = jdescale((int32_t)(tmp12 - tmp1), SHIFT);
+    out[3] = jdescale((int32_t)(tmp13 + tmp0), SHIFT); out[4] = jdescale((int32_t)(tmp13 - tmp0), SHIFT);
+}
+
+// range_limit[x & RANGE_MASK] of libjpeg's table, samples centred on 128
+__device__ __forceinline__ uint32_t range_limit_idct(int32_t x) {
+    const int y = x & 1023;
+    return (uint32_t)(y < 128 ? y + 128 : y < 512 ? 255 : y < 896 ? 0 : y - 896);
+}
+
+constexpr int kIdctBlocksPerWg = 32;
+// grid (ceil(frameBlocks / 32), frames).  A frame's planes: component 0 (bw0 * 8 bytes a row), then 1, then 2.
+__global__ __launch_bounds__(256) void k_jpeg_idct(int16_t* __restrict__ coef, const JpegDesc* __restrict__ desc,
+                                                   const uint16_t* __restrict__ quant, uint8_t* __restrict__ planes,
+                                                   uint32_t frameBlocks, const int32_t* __restrict__ frameOf) {
+    __shared__ int32_t s_ws[kIdctBlocksPerWg][8 * 9];
+    const int f = frameOf ? frameOf[blockIdx.y] : (int)blockIdx.y;
+    const JpegDesc d = desc[f];
+    const uint32_t bw0 = (uint32_t)d.mcux * d.hmax, n0 = bw0 * ((uint32_t)d.mcuy * d.vmax);
+    const uint32_t n1 = d.nc == 3 ? (uint32_t)d.mcux * d.mcuy : 0u;
+    const int g = threadIdx.x >> 3, r = threadIdx.x & 7;
+    const uint32_t slot = blockIdx.x * kIdctBlocksPerWg + (uint32_t)g;
+    if (slot >= n0 + 2u * n1) return;
+    const int c = slot < n0 ? 0 : slot < n0 + n1 ? 1 : 2;
+    const uint32_t idx = slot - (c == 0 ? 0u : c == 1 ? n0 : n0 + n1);
+    const uint32_t bw = c == 0 ? bw0 : (uint32_t)d.mcux;
+    const uint32_t brow = idx / bw, bcol = idx - brow * bw;
+    uint4* const cp = reinterpret_cast<uint4*>(coef + ((size_t)f * frameBlocks + slot) * 64 + r * 8);
+    const uint4 cv = *cp;
+    *cp = make_uint4(0, 0, 0, 0);  // (the coefficient planes are all zero between calls: k_jpeg_huff stores only what is not)
+    const uint4 qv = *reinterpret_cast<const uint4*>(quant + ((size_t)f * 4 + (c == 0 ? d.tq[0] : c == 1 ? d.tq[1] : d.tq[2])) * 64 + r * 8);
+    const uint32_t cw[4] = {cv.x, cv.y, cv.z, cv.w}, qw[4] = {qv.x, qv.y, qv.z, qv.w};
+    int32_t* const ws = s_ws[g];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        ws[r * 9 + 2 * i] = jmul((int32_t)(int16_t)(cw[i] & 0xFFFFu), (int32_t)(qw[i] & 0xFFFFu));
+        ws[r * 9 + 2 * i + 1] = jmul((int32_t)(int16_t)(cw[i] >> 16), (int32_t)(qw[i] >> 16));
+    }
+    wave_lds_order();
+    int32_t in[8], out[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) in[i] = ws[i * 9 + r];  // column r
+    idct_1d<13 - 2>(in, out);
+    wave_lds_order();
+#pragma unroll
+    for (int i = 0; i < 8; i++) ws[i * 9 + r] = out[i];
+    wave_lds_order();
+#pragma unroll
+    for (int i = 0; i < 8; i++) in[i] = ws[r * 9 + i];  // row r
+    idct_1d<13 + 2 + 3>(in, out);
+    uint2 o;
+    o.x = range_limit_idct(out[0]) | (range_limit_idct(out[1]) << 8) | (range_limit_idct(out[2]) << 16) | (range_limit_idct(out[3]) << 24);
+    o.y = range_limit_idct(out[4]) | (range_limit_idct(out[5]) << 8) | (range_limit_idct(out[6]) << 16) | (range_limit_idct(out[7]) << 24);
+    uint8_t* const plane = planes + (size_t)f * frameBlocks * 64 + (size_t)(c == 0 ? 0u : c == 1 ? n0 : n0 + n1) * 64;
+    *reinterpret_cast<uint2*>(plane + ((size_t)brow * 8 + r) * (bw * 8) + (size_t)bcol * 8) = o;
+}
+
+// ---- upsampling + colour conversion ---------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t clamp8(int v) { return (uint32_t)min(max(v, 0), 255); }
+
+// jdsample.c h2v1_fancy_upsample / h2v2_fancy_upsample as functions of the output position (the special cases at the
+// first and last column, and the context rows of jdmainct.c at the first and last row, are the general formulas with
+// the neighbour clamped into the plane); cw x ch = the component's real (downsampled) size
+__device__ __forceinline__ int chroma_at(const uint8_t* __restrict__ C, int stride, int cw, int ch, int hmax, int vmax, int x, int y) {
+    if (hmax == 1) return C[(size_t)y * stride + x];
+    const int i = x >> 1, in = (x & 1) ? min(i + 1, cw - 1) : max(i - 1, 0);
+    if (vmax == 1) {
+        const uint8_t* row = C + (size_t)y * stride;
+        return (3 * row[i] + row[in] + ((x & 1) ? 2 : 1)) >> 2;
+    }
+    const int j = y >> 1, jn = (y & 1) ? min(j + 1, ch - 1) : max(j - 1, 0);
+    const uint8_t* r0 = C + (size_t)j * stride;
+    const uint8_t* r1 = C + (size_t)jn * stride;
+    const int cur = 3 * r0[i] + r1[i], nbr = 3 * r0[in] + r1[in];
+    return (3 * cur + nbr + ((x & 1) ? 7 : 8)) >> 4;
+}
+
+// lane = four pixels of one row; grid (ceil(H * ceil(W / 4) / 256), frames)
+__global__ __launch_bounds__(256) void k_jpeg_color(const uint8_t* __restrict__ planes, const JpegDesc* __restrict__ desc,
+                                                    uint32_t frameBlocks, int H, int W, uint8_t* __restrict__ out,
+                                                    const int32_t* __restrict__ frameOf) {
+    const int f = frameOf ? frameOf[blockIdx.y] : (int)blockIdx.y;
+    const int W4 = (W + 3) >> 2;
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= (uint32_t)(H * W4)) return;
+    const int y = (int)(t / (uint32_t)W4), x0 = (int)(t - (uint32_t)y * W4) * 4;
+    const JpegDesc d = desc[f];
+    const uint32_t bw0 = (uint32_t)d.mcux * d.hmax, n0 = bw0 * ((uint32_t)d.mcuy * d.vmax), n1 = (uint32_t)d.mcux * d.mcuy;
+    const uint8_t* const Y = planes + (size_t)f * frameBlocks * 64;
+    const int ys = (int)bw0 * 8;
+    uint32_t px[4];
+    const uint32_t yw = *reinterpret_cast<const uint32_t*>(Y + (size_t)y * ys + x0);  // (the plane is padded to whole blocks)
+    if (d.nc == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) px[i] = ((yw >> (8 * i)) & 255u) * 0x010101u;
+    } else {
+        const uint8_t* const Cb = Y + (size_t)n0 * 64;
+        const uint8_t* const Cr = Cb + (size_t)n1 * 64;
+        const int cs = (int)d.mcux * 8, cw = (W + d.hmax - 1) / d.hmax, ch = (H + d.vmax - 1) / d.vmax;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int x = min(x0 + i, W - 1);
+            const int yy = (int)((yw >> (8 * i)) & 255u);
+            const int cb = chroma_at(Cb, cs, cw, ch, d.hmax, d.vmax, x, y) - 128;
+            const int cr = chroma_at(Cr, cs, cw, ch, d.hmax, d.vmax, x, y) - 128;
+            // jdcolor.c: FIX(1.40200) = 91881, FIX(1.77200) = 116130, FIX(0.71414) = 46802, FIX(0.34414) = 22554
+            const uint32_t R = clamp8(yy + ((91881 * cr + 32768) >> 16));
+            const uint32_t G = clamp8(yy + ((-22554 * cb + 32768 - 46802 * cr) >> 16));
+            const uint32_t B = clamp8(yy + ((116130 * cb + 32768) >> 16));
+            px[i] = B | (G << 8) | (R << 16);
+        }
+    }
+    const size_t pix = (size_t)f * H * W + (size_t)y * W + x0;
+    uint8_t* const o = out + pix * 3;
+    if (x0 + 3 < W && (pix & 3u) == 0) {  // (12 bytes, 4-byte aligned when the pixel index is a multiple of 4: `out` is)
+        uint32_t* o32 = reinterpret_cast<uint32_t*>(o);
+        o32[0] = px[0] | (px[1] << 24);
+        o32[1] = (px[1] >> 8) | (px[2] << 16);
+        o32[2] = (px[2] >> 16) | (px[3] << 8);
+    } else {
+        for (int i = 0; i < 4 && x0 + i < W; i++) {
+            o[3 * i] = (uint8_t)px[i];
+            o[3 * i + 1] = (uint8_t)(px[i] >> 8);
+            o[3 * i + 2] = (uint8_t)(px[i] >> 16);
+        }
+    }
+}
+
+// ---- host: headers, tables, buffers -----------------------------------------------------------------------------------
+
+// ITU T.81 Annex K.3: the tables a frame without DHT segments means (MJPEG)
+const uint8_t kStdDcLumBits[16] = {0, 1, 5, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0};
+const uint8_t kStdDcChrBits[16] = {0, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0};
+const uint8_t kStdDcVal[12] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11};
+const uint8_t kStdAcLumBits[16] = {0, 2, 1, 3, 3, 2, 4, 3, 5, 5, 4, 4, 0, 0, 1, 0x7d};
+const uint8_t kStdAcLumVal[162] = {
+    0x01, 0x02, 0x03, 0x00, 0x04, 0x11, 0x05, 0x12, 0x21, 0x31, 0x41, 0x06, 0x13, 0x51, 0x61, 0x07, 0x22, 0x71,
+    0x14, 0x32, 0x81, 0x91, 0xa1, 0x08, 0x23, 0x42, 0xb1, 0xc1, 0x15, 0x52, 0xd1, 0xf0, 0x24, 0x33, 0x62, 0x72,
+    0x82, 0x09, 0x0a, 0x16, 0x17, 0x18, 0x19, 0x1a, 0x25, 0x26, 0x27, 0x28, 0x29, 0x2a, 0x34, 0x35, 0x36, 0x37,
+    0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48, 0x49, 0x4a, 0x53, 0x54, 0x55, 0x56, 0x57, 0x58, 0x59,
+    0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69, 0x6a, 0x73, 0x74, 0x75, 0x76, 0x77, 0x78, 0x79, 0x7a, 0x83,
+    0x84, 0x85, 0x86, 0x87, 0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a, 0xa2, 0xa3,
+    0xa4, 0xa5, 0xa6, 0xa7, 0xa8, 0xa9, 0xaa, 0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba, 0xc2, 0xc3,
+    0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3, 0xd4, 0xd5, 0xd6, 0xd7, 0xd8, 0xd9, 0xda, 0xe1, 0xe2,
+    0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf1, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9, 0xfa};
+const uint8_t kStdAcChrBits[16] = {0, 2, 1, 2, 4, 4, 3, 4, 7, 5, 4, 4, 0, 1, 2, 0x77};
+const uint8_t kStdAcChrVal[162] = {
+    0x00, 0x01, 0x02, 0x03, 0x11, 0x04, 0x05, 0x21, 0x31, 0x06, 0x12, 0x41, 0x51, 0x07, 0x61, 0x71, 0x13, 0x22,
+    0x32, 0x81, 0x08, 0x14, 0x42, 0x91, 0xa1, 0xb1, 0xc1, 0x09, 0x23, 0x33, 0x52, 0xf0, 0x15, 0x62, 0x72, 0xd1,
+    0x0a, 0x16, 0x24, 0x34, 0xe1, 0x25, 0xf1, 0x17, 0x18, 0x19, 0x1a, 0x26, 0x27, 0x28, 0x29, 0x2a, 0x35, 0x36,
+    0x37, 0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48, 0x49, 0x4a, 0x53, 0x54, 0x55, 0x56, 0x57, 0x58,
+    0x59, 0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69, 0x6a, 0x73, 0x74, 0x75, 0x76, 0x77, 0x78, 0x79, 0x7a,
+    0x82, 0x83, 0x84, 0x85, 0x86, 0x87, 0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a,
+    0xa2, 0xa3, 0xa4, 0xa5, 0xa6, 0xa7, 0xa8, 0xa9, 0xaa, 0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba,
+    0xc2, 0xc3, 0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3, 0xd4, 0xd5, 0xd6, 0xd7, 0xd8, 0xd9, 0xda,
+    0xe2, 0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9, 0xfa};
+
+struct HuffSpec {  // a DHT table as the file gives it
+    bool set = false;
+    uint8_t bits[16];
+    uint8_t vals[256];
+    int total = 0;
+    void assign(const uint8_t* b, const uint8_t* v, int n) {
+        memcpy(bits, b, 16);
+        memcpy(vals, v, (size_t)n);
+        total = n;
+        set = true;
+    }
+    std::string key() const { return std::string(reinterpret_cast<const char*>(bits), 16) + std::string(reinterpret_cast<const char*>(vals), (size_t)total); }
+};
+
+// the device form of a table (kHuffTableBytes); false if the code lengths are not a prefix code
+bool build_table(const HuffSpec& h, uint8_t* out) {
+    memset(out, 0, kHuffTableBytes);
+    uint16_t* look = reinterpret_cast<uint16_t*>(out);
+    int32_t* maxcode = reinterpret_cast<int32_t*>(out + kOffMaxcode);
+    int32_t* valoff = reinterpret_cast<int32_t*>(out + kOffValoff);
+    memcpy(out + kOffHuffval, h.vals, (size_t)h.total);
+    int code = 0, p = 0;
+    for (int l = 1; l <= 16; l++) {
+        const int n = h.bits[l - 1];
+        if (n) {
+            valoff[l] = p - code;
+            if (l <= 8)
+                for (int i = 0; i < n; i++)
+                    for (int j = 0; j < (1 << (8 - l)); j++) look[((code + i) << (8 - l)) + j] = (uint16_t)((l << 8) | h.vals[p + i]);
+            p += n;
+            code += n;
+            maxcode[l] = code - 1;
+        } else {
+            maxcode[l] = -1;
+        }
+        if (code > (1 << l)) return false;
+        code <<= 1;
+    }
+    maxcode[17] = 0x7FFFFFFF;
+    return true;
+}
+
+struct ParsedFrame {
+    JpegDesc d{};
+    uint16_t quant[4][64];
+    size_t scanOff = 0;  // first entropy-coded byte in the file
+    HuffSpec dc[3], ac[3];  // by slot
+};
+
+// 0, or an error text
+const char* parse_frame(const uint8_t* data, size_t n, int H, int W, ParsedFrame& out) {
+    if (!data || n < 4 || data[0] != 0xFF || data[1] != 0xD8) return "not a JPEG (no SOI marker)";
+    bool qset[4] = {false, false, false, false};
+    HuffSpec dcT[4], acT[4];
+    bool anyDht = false;
+    int nc = 0, compId[3] = {0, 0, 0}, compH[3] = {1, 1, 1}, compV[3] = {1, 1, 1}, td[3] = {0, 0, 0}, ta[3] = {0, 0, 0};
+    int h = 0, w = 0, restart = 0;
+    size_t i = 2, scan = 0;
+    memset(out.quant, 0, sizeof out.quant);
+    while (!scan) {
+        if (i + 4 > n || data[i] != 0xFF) return "truncated or damaged headers";
+        const int m = data[i + 1];
+        if (m == 0xFF) { i++; continue; }
+        if (m == 0xD8 || (m >= 0xD0 && m <= 0xD7) || m == 0x01) { i += 2; continue; }
+        const size_t L = ((size_t)data[i + 2] << 8) | data[i + 3];
+        if (L < 2 || i + 2 + L > n) return "truncated or damaged headers";
+        const uint8_t* s = data + i + 4;
+        const size_t len = L - 2;
+        if (m == 0xDB) {
+            size_t k = 0;
+            while (k < len) {
+                const int pq = s[k] >> 4, tq = s[k] & 15;
+                if (tq > 3 || pq > 1 || k + 1 + (pq ? 128u : 64u) > len) return "bad quantisation table";
+                for (int j = 0; j < 64; j++)
+                    out.quant[tq][h_zigzag[j]] = pq ? (uint16_t)((s[k + 1 + 2 * j] << 8) | s[k + 2 + 2 * j]) : s[k + 1 + j];
+                qset[tq] = true;
+                k += 1 + (pq ? 128 : 64);
+            }
+        } else if (m == 0xC0 || m == 0xC1) {
+            if (len < 6 || s[0] != 8) return "only 8-bit samples are supported";
+            h = (s[1] << 8) | s[2];
+            w = (s[3] << 8) | s[4];
+            nc = s[5];
+            if ((nc != 1 && nc != 3) || len < 6 + 3 * (size_t)nc) return "only 1 or 3 components (Y / YCbCr) are supported";
+            for (int c = 0; c < nc; c++) {
+                compId[c] = s[6 + 3 * c];
+                compH[c] = s[7 + 3 * c] >> 4;
+                compV[c] = s[7 + 3 * c] & 15;
+                out.d.tq[c] = s[8 + 3 * c];
+                if (out.d.tq[c] > 3) return "bad quantisation table selector";
+            }
+        } else if (m == 0xC4) {
+            size_t k = 0;
+            while (k < len) {
+                if (k + 17 > len) return "bad Huffman table";
+                const int tc = s[k] >> 4, th = s[k] & 15;
+                int total = 0;
+                for (int l = 0; l < 16; l++) total += s[k + 1 + l];
+                if (tc > 1 || th > 3 || total > 256 || k + 17 + (size_t)total > len) return "bad Huffman table";
+                (tc ? acT[th] : dcT[th]).assign(s + k + 1, s + k + 17, total);
+                anyDht = true;
+                k += 17 + (size_t)total;
+            }
+        } else if (m == 0xDD) {
+            if (len < 2) return "bad restart interval";
+            restart = (s[0] << 8) | s[1];
+        } else if (m == 0xDA) {
+            if (!nc || len < 1 || s[0] != nc || len < 1 + 2 * (size_t)nc + 3) return "only one interleaved scan with every component is supported";
+            for (int c = 0; c < nc; c++) {
+                if (s[1 + 2 * c] != compId[c]) return "only one interleaved scan with every component is supported";
+                td[c] = s[2 + 2 * c] >> 4;
+                ta[c] = s[2 + 2 * c] & 15;
+                if (td[c] > 3 || ta[c] > 3) return "bad Huffman table selector";
+            }
+            if (s[1 + 2 * nc] != 0 || s[2 + 2 * nc] != 63 || s[3 + 2 * nc] != 0) return "not a sequential scan";
+            scan = i + 2 + L;
+        } else if (m == 0xC2 || (m >= 0xC3 && m <= 0xCF && m != 0xC8)) {
+            return "progressive, lossless and arithmetic-coded JPEG are not supported (baseline / MJPEG frames only)";
+        }
+        i += 2 + L;
+    }
+    if (h != H || w != W) return "frame size differs from the batch's";
+    if (!anyDht) {
+        dcT[0].assign(kStdDcLumBits, kStdDcVal, 12);
+        dcT[1].assign(kStdDcChrBits, kStdDcVal, 12);
+        acT[0].assign(kStdAcLumBits, kStdAcLumVal, 162);
+        acT[1].assign(kStdAcChrBits, kStdAcChrVal, 162);
+    }
+    if (nc == 1) compH[0] = compV[0] = 1;
+    const int hmax = compH[0], vmax = compV[0];
+    if (nc == 3) {
+        if (compH[1] != 1 || compV[1] != 1 || compH[2] != 1 || compV[2] != 1 ||
+            !((hmax == 1 && vmax == 1) || (hmax == 2 && vmax == 1) || (hmax == 2 && vmax == 2)))
+            return "chroma sampling other than 4:4:4, 4:2:2 and 4:2:0 is not supported";
+    }
+    // the tables the components use, as slots of the frame's table set
+    int dcSlotOf[4] = {-1, -1, -1, -1}, acSlotOf[4] = {-1, -1, -1, -1}, nd = 0, na = 0;
+    for (int c = 0; c < nc; c++) {
+        if (!qset[out.d.tq[c]] || !dcT[td[c]].set || !acT[ta[c]].set) return "a table the scan refers to is missing";
+        if (dcSlotOf[td[c]] < 0) { dcSlotOf[td[c]] = nd; out.dc[nd++] = dcT[td[c]]; }
+        if (acSlotOf[ta[c]] < 0) { acSlotOf[ta[c]] = na; out.ac[na++] = acT[ta[c]]; }
+        out.d.td[c] = (uint8_t)dcSlotOf[td[c]];
+        out.d.ta[c] = (uint8_t)acSlotOf[ta[c]];
+    }
+    out.d.nc = (uint8_t)nc;
+    out.d.hmax = (uint8_t)hmax;
+    out.d.vmax = (uint8_t)vmax;
+    out.d.mcux = (uint16_t)((W + 8 * hmax - 1) / (8 * hmax));
+    out.d.mcuy = (uint16_t)((H + 8 * vmax - 1) / (8 * vmax));
+    out.d.restart = (uint16_t)restart;
+    out.scanOff = scan;
+    return nullptr;
+}
+
+template <class T>
+bool regrow_dev(T*& p, size_t& cap, size_t need) {
+    if (need <= cap) return true;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    const size_t n = need + need / 4;
+    if (hipMalloc(reinterpret_cast<void**>(&p), n * sizeof(T)) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    cap = n;
+    return true;
+}
+
+}  // namespace
+
+struct JpegState {
+    uint8_t* d_bytes = nullptr; size_t bytesCap = 0;
+    uint8_t* h_bytes = nullptr; size_t hBytesCap = 0;  // page-locked
+    JpegDesc* d_desc = nullptr; size_t descCap = 0;
+    uint16_t* d_quant = nullptr; size_t quantCap = 0;
+    uint8_t* d_tables = nullptr; size_t tablesCap = 0;
+    int32_t* d_groups = nullptr; size_t groupsCap = 0;
+    int32_t* d_status = nullptr; size_t statusCap = 0;
+    int16_t* d_coef = nullptr; size_t coefCap = 0;   // [frames][frameBlocks][64], all zero between calls
+    uint8_t* d_planes = nullptr; size_t planesCap = 0;
+    uint8_t* d_out = nullptr; size_t outCap = 0;      // BGR frames when the caller's output is on the host
+    bool coefDirty = false;
+};
+
+JpegState* jpeg_create() { return new JpegState(); }
+
+void jpeg_destroy(JpegState* s) {
+    if (!s) return;
+    void* ptrs[] = {s->d_bytes, s->d_desc, s->d_quant, s->d_tables, s->d_groups, s->d_status, s->d_coef, s->d_planes, s->d_out};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    if (s->h_bytes) (void)hipHostFree(s->h_bytes);
+    delete s;
+}
+
+int jpeg_info(const uint8_t* data, size_t n, int32_t* height, int32_t* width, int32_t* components) {
+    if (!data || n < 4 || data[0] != 0xFF || data[1] != 0xD8) return CAMSYNC_E_ARG;
+    size_t i = 2;
+    while (i + 4 <= n) {
+        if (data[i] != 0xFF) return CAMSYNC_E_ARG;
+        const int m = data[i + 1];
+        if (m == 0xFF) { i++; continue; }
+        if (m == 0xD8 || (m >= 0xD0 && m <= 0xD7) || m == 0x01) { i += 2; continue; }
+        const size_t L = ((size_t)data[i + 2] << 8) | data[i + 3];
+        if (m >= 0xC0 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) {
+            if (i + 2 + L > n || L < 8) return CAMSYNC_E_ARG;
+            if (height) *height = (data[i + 5] << 8) | data[i + 6];
+            if (width) *width = (data[i + 7] << 8) | data[i + 8];
+            if (components) *components = data[i + 9];
+            return CAMSYNC_OK;
+        }
+        if (m == 0xDA) return CAMSYNC_E_ARG;
+        i += 2 + L;
+    }
+    return CAMSYNC_E_ARG;
+}
+
+// B frames of H x W -> out [B,H,W,3] (device pointer if outOnDevice, else host).  Enqueues on st and waits for it.
+int jpeg_decode_batch(JpegState* s, hipStream_t st, const uint8_t* const* jpegs, const size_t* sizes, int B, int H, int W,
+                      uint8_t* out, int outOnDevice, std::string& err) {
+    auto hipfail = [&](const char* what, hipError_t e) {
+        err = std::string(what) + ": " + hipGetErrorString(e);
+        return CAMSYNC_E_HIP;
+    };
+    const uint32_t maxBW = 2u * (uint32_t)((W + 15) / 16), maxBH = 2u * (uint32_t)((H + 15) / 16);
+    const size_t frameCoefBytes = (size_t)3u * maxBW * maxBH * 128;  // (4:4:4, the largest of the supported samplings)
+    // frames per pass: the coefficient planes of a pass stay under 48 GB (the Huffman kernel's time hardly depends on
+    // how many frames it decodes side by side, so a pass takes as many as fit)
+    const int chunk = (int)std::max<size_t>(64, std::min<size_t>((size_t)B, ((size_t)48 << 30) / frameCoefBytes));
+    std::vector<ParsedFrame> pf;
+    std::vector<JpegDesc> descs;
+    std::vector<uint16_t> quant;
+    std::vector<int32_t> groups, status;
+    for (int b0 = 0; b0 < B; b0 += chunk) {
+        const int nb = std::min(chunk, B - b0);
+        pf.assign((size_t)nb, ParsedFrame());
+        size_t totalBytes = 0;
+        for (int i = 0; i < nb; i++) {
+            const char* e = parse_frame(jpegs[b0 + i], sizes[b0 + i], H, W, pf[(size_t)i]);
+            if (e) {
+                char tmp[256];
+                snprintf(tmp, sizeof tmp, "frame %d: %s", b0 + i, e);
+                err = tmp;
+                return CAMSYNC_E_ARG;
+            }
+            pf[(size_t)i].d.dataOff = (uint32_t)totalBytes;
+            pf[(size_t)i].d.dataLen = (uint32_t)(sizes[b0 + i] - pf[(size_t)i].scanOff);
+            totalBytes += (pf[(size_t)i].d.dataLen + 15u) & ~(size_t)15u;
+            if (totalBytes > 0xFFFF0000ull) { err = "more than 4 GiB of compressed data in one pass"; return CAMSYNC_E_ARG; }
+        }
+        totalBytes += 16;  // (the bit reader fetches four bytes at a time)
+        // blocks per frame of this pass: the largest of its frames' layouts
+        uint32_t frameBlocks = 0;
+        for (int i = 0; i < nb; i++) {
+            const JpegDesc& d = pf[(size_t)i].d;
+            frameBlocks = std::max(frameBlocks, (uint32_t)d.mcux * d.hmax * d.mcuy * d.vmax + (d.nc == 3 ? 2u * d.mcux * d.mcuy : 0u));
+        }
+        // ---- table sets, groups of 64 frames that share one ----
+        std::map<std::string, int> setIndex;
+        std::vector<uint8_t> tables;
+        std::vector<std::vector<int>> framesOfSet;
+        for (int i = 0; i < nb; i++) {
+            const ParsedFrame& p = pf[(size_t)i];
+            std::string key;
+            for (int t = 0; t < 3; t++) key += p.dc[t].set ? p.dc[t].key() : std::string("-");
+            for (int t = 0; t < 3; t++) key += p.ac[t].set ? p.ac[t].key() : std::string("-");
+            auto it = setIndex.find(key);
+            if (it == setIndex.end()) {
+                const int id = (int)framesOfSet.size();
+                it = setIndex.emplace(key, id).first;
+                framesOfSet.emplace_back();
+                tables.resize(tables.size() + (size_t)kHuffSetTables * kHuffTableBytes, 0);
+                uint8_t* base = tables.data() + (size_t)id * kHuffSetTables * kHuffTableBytes;
+                for (int t = 0; t < 3; t++) {
+                    if (p.dc[t].set && !build_table(p.dc[t], base + (size_t)t * kHuffTableBytes)) { err = "a Huffman table is not a prefix code"; return CAMSYNC_E_ARG; }
+                    if (p.ac[t].set && !build_table(p.ac[t], base + (size_t)(3 + t) * kHuffTableBytes)) { err = "a Huffman table is not a prefix code"; return CAMSYNC_E_ARG; }
+                }
+            }
+            framesOfSet[(size_t)it->second].push_back(i);
+        }
+        groups.clear();
+        for (size_t set = 0; set < framesOfSet.size(); set++)
+            for (size_t k = 0; k < framesOfSet[set].size(); k += 64) {
+                groups.push_back((int32_t)set);
+                for (size_t j = 0; j < 64; j++) groups.push_back(k + j < framesOfSet[set].size() ? framesOfSet[set][k + j] : -1);
+            }
+        const int nGroups = (int)(groups.size() / 65);
+        descs.resize((size_t)nb);
+        quant.resize((size_t)nb * 256);
+        for (int i = 0; i < nb; i++) {
+            descs[(size_t)i] = pf[(size_t)i].d;
+            memcpy(&quant[(size_t)i * 256], pf[(size_t)i].quant, 512);
+        }
+        // ---- buffers ----
+        if (totalBytes > s->hBytesCap) {
+            if (s->h_bytes) (void)hipHostFree(s->h_bytes);
+            s->h_bytes = nullptr;
+            s->hBytesCap = 0;
+            const size_t n = totalBytes + totalBytes / 4;
+            hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&s->h_bytes), n, hipHostMallocDefault);
+            if (e != hipSuccess) return hipfail("hipHostMalloc(compressed frames)", e);
+            s->hBytesCap = n;
+        }
+        const size_t coefNeed = (size_t)nb * frameBlocks * 64;
+        const bool freshCoef = coefNeed > s->coefCap;
+        if (!regrow_dev(s->d_bytes, s->bytesCap, totalBytes) || !regrow_dev(s->d_desc, s->descCap, (size_t)nb) ||
+            !regrow_dev(s->d_quant, s->quantCap, (size_t)nb * 256) || !regrow_dev(s->d_tables, s->tablesCap, tables.size()) ||
+            !regrow_dev(s->d_groups, s->groupsCap, groups.size()) || !regrow_dev(s->d_status, s->statusCap, (size_t)nb) ||
+            !regrow_dev(s->d_coef, s->coefCap, coefNeed) || !regrow_dev(s->d_planes, s->planesCap, (size_t)nb * frameBlocks * 64) ||
+            (!outOnDevice && !regrow_dev(s->d_out, s->outCap, (size_t)nb * H * W * 3))) {
+            err = "out of device memory for the JPEG decoder's buffers";
+            return CAMSYNC_E_HIP;
+        }
+        hipError_t e;
+        if (freshCoef || s->coefDirty) {
+            if ((e = hipMemsetAsync(s->d_coef, 0, s->coefCap * sizeof(int16_t), st)) != hipSuccess) return hipfail("hipMemsetAsync", e);
+            s->coefDirty = false;
+        }
+        memset(s->h_bytes, 0, totalBytes);
+        for (int i = 0; i < nb; i++)
+            memcpy(s->h_bytes + pf[(size_t)i].d.dataOff, jpegs[b0 + i] + pf[(size_t)i].scanOff, pf[(size_t)i].d.dataLen);
+        if ((e = hipMemcpyAsync(s->d_bytes, s->h_bytes, totalBytes, hipMemcpyHostToDevice, st)) != hipSuccess) return hipfail("hipMemcpyAsync", e);
+        if ((e = hipMemcpyAsync(s->d_desc, descs.data(), sizeof(JpegDesc) * nb, hipMemcpyHostToDevice, st)) != hipSuccess) return hipfail("hipMemcpyAsync", e);
+        if ((e = hipMemcpyAsync(s->d_quant, quant.data(), quant.size() * 2, hipMemcpyHostToDevice, st)) != hipSuccess) return hipfail("hipMemcpyAsync", e);
+        if ((e = hipMemcpyAsync(s->d_tables, tables.data(), tables.size(), hipMemcpyHostToDevice, st)) != hipSuccess) return hipfail("hipMemcpyAsync", e);
+        if ((e = hipMemcpyAsync(s->d_groups, groups.data(), groups.size() * 4, hipMemcpyHostToDevice, st)) != hipSuccess) return hipfail("hipMemcpyAsync", e);
+        if ((e = hipMemsetAsync(s->d_status, 0, sizeof(int32_t) * nb, st)) != hipSuccess) return hipfail("hipMemsetAsync", e);
+        // ---- the three kernels ----
+        uint8_t* const dst = outOnDevice ? out + (size_t)b0 * H * W * 3 : s->d_out;
+        s->coefDirty = true;  // (until the inverse DCT has put the zeros back)
+        hipLaunchKernelGGL(k_jpeg_huff, dim3((unsigned)nGroups), dim3(64), 0, st, s->d_bytes, s->d_desc, s->d_groups, s->d_tables,
+                           s->d_coef, frameBlocks, s->d_status);
+        hipLaunchKernelGGL(k_jpeg_idct, dim3((frameBlocks + kIdctBlocksPerWg - 1) / kIdctBlocksPerWg, (unsigned)nb), dim3(256), 0, st,
+                           s->d_coef, s->d_desc, s->d_quant, s->d_planes, frameBlocks, (const int32_t*)nullptr);
+        const unsigned colorBlocks = (unsigned)(((size_t)H * ((W + 3) / 4) + 255) / 256);
+        hipLaunchKernelGGL(k_jpeg_color, dim3(colorBlocks, (unsigned)nb), dim3(256), 0, st, s->d_planes, s->d_desc, frameBlocks, H, W,
+                           dst, (const int32_t*)nullptr);
+        if ((e = hipGetLastError()) != hipSuccess) return hipfail("JPEG kernels", e);
+        status.assign((size_t)nb, 0);
+        if ((e = hipMemcpyAsync(status.data(), s->d_status, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, st)) != hipSuccess) return hipfail("hipMemcpyAsync", e);
+        if (!outOnDevice)
+            if ((e = hipMemcpyAsync(out + (size_t)b0 * H * W * 3, s->d_out, (size_t)nb * H * W * 3, hipMemcpyDeviceToHost, st)) != hipSuccess) return hipfail("hipMemcpyAsync", e);
+        if ((e = hipStreamSynchronize(st)) != hipSuccess) return hipfail("hipStreamSynchronize", e);
+        s->coefDirty = false;  // every block the Huffman kernel may have touched has been through k_jpeg_idct
+        for (int i = 0; i < nb; i++)
+            if (status[(size_t)i]) {
+                char tmp[128];
+                snprintf(tmp, sizeof tmp, "frame %d: corrupt entropy-coded data", b0 + i);
+                err = tmp;
+                return CAMSYNC_E_ARG;
+            }
+    }
+    return CAMSYNC_OK;
+}
+
+}  // namespace camsync

@@ -94,6 +94,20 @@ int camsync_host_free(void* p);
 int camsync_ingest_yuyv(camsync_ctx* ctx, const uint8_t* yuyv, int in_on_device, int B, int H, int W,
                         uint8_t* bgr, int out_on_device);
 
+/* Compressed frames: what cv.VideoCapture(...).read() does on a camera that delivers MJPG, and cv.imread on the
+ * reference's stored photos (camera.py:98-118, 150-154; pics/ *.jpg): baseline JPEG -> BGR, decoded as libjpeg-turbo
+ * does with its defaults (accurate integer IDCT, triangle-filter chroma upsampling, fixed-point YCbCr -> RGB).
+ * jpegs: B host pointers to one JPEG file / MJPEG frame each, sizes[B] their lengths; all frames H x W (the SOF size;
+ * camsync_jpeg_info reads it from a header, host only, no context).  bgr u8 [B,H,W,3], on the host or (out_on_device,
+ * 4-byte aligned) left on the GPU for the on_device / _resident entry points.  Taken: SOF0 / SOF1, 8-bit, one
+ * interleaved scan, 1 or 3 components (Y / YCbCr), 4:4:4 / 4:2:2 / 4:2:0, restart intervals, frames without DHT segments
+ * (the Annex K tables); anything else (progressive, arithmetic coding, CMYK, ...) is CAMSYNC_E_ARG with a message naming
+ * the frame, and so is corrupt entropy-coded data.  The frames of a batch are decoded side by side (a frame's Huffman
+ * stream is sequential): large batches are what makes this fast. */
+int camsync_jpeg_info(const uint8_t* data, size_t n, int32_t* height, int32_t* width, int32_t* components);
+int camsync_decode_jpeg_batch(camsync_ctx* ctx, const uint8_t* const* jpegs, const size_t* sizes, int B, int H, int W,
+                              uint8_t* bgr, int out_on_device);
+
 /* cv.aruco.DetectorParameters() (aruco.py:249-254). */
 void camsync_default_params(camsync_params* p);
 int camsync_set_params(camsync_ctx* ctx, const camsync_params* p);

@@ -102,3 +102,62 @@ def test_what_the_decoder_does_not_take():
         orc.jpeg_decode(b"\x89PNG....")
     with pytest.raises(ValueError):
         orc.jpeg_decode(_encode(img, quality=80)[:200])
+
+
+# ---- GPU: camsync_decode_jpeg_batch against the oracle -----------------------------------------------------------------
+
+@pytest.mark.gpu
+def test_gpu_decodes_the_reference_photos_like_the_oracle():
+    from cameracalibration_amd import _hip
+    datas = [open(f, "rb").read() for f in _reference_jpegs()]
+    assert _hip.jpeg_info(datas[0]) == (480, 640, 3)
+    ctx = _hip.Context(480, 640, 32)
+    got = ctx.decode_jpeg(datas)
+    assert got.shape == (21, 480, 640, 3)
+    for i, d in enumerate(datas):
+        assert np.array_equal(got[i], orc.jpeg_decode(d)), i
+    # and what the decoded frames are for: the photos of the marker sheet give the oracle's detections
+    again = ctx.decode_jpeg(datas[9:17])
+    assert np.array_equal(again, got[9:17])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hw", [(48, 64), (50, 70), (33, 47), (8, 8), (17, 250), (480, 640)])
+def test_gpu_decodes_every_supported_kind_like_the_oracle(hw):
+    """One batch that mixes samplings, table sets (standard, optimised, none), restart intervals and gray frames."""
+    from cameracalibration_amd import _hip
+    img = _scene(hw[0], hw[1], hw[0] * 1000 + hw[1])
+    datas = [_encode(img, **kw) for kw in VARIANTS]
+    datas.append(_encode(img[..., 0], quality=80))
+    datas.append(strip_dht(_encode(img, quality=80, subsampling=1)))
+    datas += [_encode(_scene(hw[0], hw[1], s), quality=70 + s, subsampling=s % 3) for s in range(70)]  # more than one group of 64
+    ctx = _hip.Context(max(hw[0], 32), max(hw[1], 32), 8)
+    got = ctx.decode_jpeg(datas)
+    for i, d in enumerate(datas):
+        assert np.array_equal(got[i], orc.jpeg_decode(d)), i
+    # frames left on the device
+    import torch
+    dev = torch.empty((len(datas),) + hw + (3,), dtype=torch.uint8, device="cuda:0")
+    assert ctx.decode_jpeg(datas, d_bgr_ptr=dev.data_ptr()) == (len(datas),) + hw + (3,)
+    torch.cuda.synchronize()
+    assert np.array_equal(dev.cpu().numpy(), got)
+
+
+@pytest.mark.gpu
+def test_gpu_refuses_what_the_decoder_does_not_take():
+    from cameracalibration_amd import _hip
+    img = _scene(48, 64, 3)
+    ctx = _hip.Context(64, 64, 4)
+    good = _encode(img, quality=80)
+    for bad in (_encode(img, progressive=True), good[:300], _encode(_scene(40, 64, 1), quality=80)):
+        with pytest.raises(_hip.CamsyncError) as e:
+            ctx.decode_jpeg([good, bad])
+        assert e.value.code == _hip.E_ARG
+    # entropy-coded data cut short or damaged: the marker / end of data feeds zeros (as libjpeg does) or the frame is
+    # reported as corrupt; either way the call returns and the context stays usable
+    cut = good[:len(good) // 2]
+    try:
+        ctx.decode_jpeg([cut])
+    except _hip.CamsyncError as e2:
+        assert e2.code == _hip.E_ARG
+    assert np.array_equal(ctx.decode_jpeg([good])[0], orc.jpeg_decode(good))
