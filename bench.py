@@ -431,6 +431,7 @@ def main():
                 out["photo_scene"] = bench_extra.leg_photo(torch, dev, 4096, 3, oracle_frames=0 if args.no_cpu else 16)
                 out["config5_8cams"] = {"1920x1080": bench_extra.leg_8cams(dev, 1080, 1920, "Logitec_robot", 10, 100),
                                         "1280x720": bench_extra.leg_8cams(dev, 720, 1280, "Logitec_A", 0, 100)}
+                out["mjpeg_ingest"] = bench_extra.leg_mjpeg(torch, dev, oracle_frames=0 if args.no_cpu else 4)
             for k in ("config2_4k", "photo_scene"):
                 out[k].pop("lists_used_and_capacity", None)
         print(json.dumps(out))

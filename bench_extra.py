@@ -216,6 +216,63 @@ def leg_8cams(dev, h, w, camname, focus, sets=200):
         return {"error": "%s: %s" % (type(e).__name__, e)}
 
 
+def leg_mjpeg(torch, dev, n=4096, h=1080, w=1920, steps=3, distinct=32, quality=85, cpu_frames=24, oracle_frames=0):
+    """Compressed ingest: n MJPEG frames (rendered views of the v1 sheet, encoded at 4:2:2 with Pillow = libjpeg-turbo,
+    Huffman tables stripped as a camera sends them) decoded to BGR frames that stay on the GPU.  The compressed bytes
+    start in host memory (that is where a capture delivers them), so the figure includes the copy of the compressed
+    data and the host-side header parse.  Beside it: libjpeg-turbo itself on one host core (Pillow), the decoder
+    cv.VideoCapture.read() uses."""
+    import io
+    from PIL import Image
+    from cameracalibration_amd import _hip, synth
+    try:
+        K = np.load(os.path.join(ROOT, "cameracalibration_amd", "camera_sync", "calibration", "Logitec_robot_1920-1080_10.npz"))["mtx"]
+        datas = []
+        for i in range(distinct):
+            img = synth.v1_frame(500 + i, np.asarray(K, np.float64), H=h, W=w, device=dev, ss=2)[0].cpu().numpy()
+            b = io.BytesIO()
+            Image.fromarray(np.ascontiguousarray(img[:, :, ::-1])).save(b, "JPEG", quality=quality, subsampling=1)
+            d = b.getvalue()
+            # drop the DHT segments (the standard tables: what an MJPEG frame means without them)
+            out = bytearray(d[:2])
+            k = 2
+            while d[k + 1] != 0xDA:
+                L = (d[k + 2] << 8) | d[k + 3]
+                if d[k + 1] != 0xC4:
+                    out += d[k:k + 2 + L]
+                k += 2 + L
+            datas.append(bytes(out + d[k:]))
+        frames = [datas[i % distinct] for i in range(n)]
+        ctx = _hip.Context(h, w, 8, 0)
+        dst = torch.empty((n, h, w, 3), dtype=torch.uint8, device=dev)
+        ctx.decode_jpeg(frames, d_bgr_ptr=dst.data_ptr())  # warm-up: buffers
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ctx.decode_jpeg(frames, d_bgr_ptr=dst.data_ptr())
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        res = {"frames": n, "height": h, "width": w, "frames_per_s": n / dt, "ms_per_batch": dt * 1e3,
+               "compressed_bytes_per_frame": int(np.mean([len(d) for d in datas])),
+               "compressed_GB_per_s": sum(len(f) for f in frames) / dt / 1e9,
+               "note": "MJPEG frames (4:2:2, quality %d, no DHT segments) in host memory -> BGR frames resident on the GPU; "
+                       "%d distinct frames repeated" % (quality, distinct)}
+        # the reference's decoder on one host core
+        t0 = time.perf_counter()
+        for i in range(cpu_frames):
+            np.asarray(Image.open(io.BytesIO(frames[i])).convert("RGB"))
+        res["cpu_libjpeg_turbo_1_core_frames_per_s"] = cpu_frames / (time.perf_counter() - t0)
+        if oracle_frames:
+            from tests import _oracle as orc
+            got = dst[:oracle_frames].cpu().numpy()
+            res["oracle_frames_compared"] = oracle_frames
+            res["oracle_frames_equal"] = int(sum(np.array_equal(got[i], orc.jpeg_decode(frames[i])) for i in range(oracle_frames)))
+        ctx.close()
+        return res
+    except Exception as e:
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames4k", type=int, default=256, help="frames of the 4K configuration (0 = skip)")

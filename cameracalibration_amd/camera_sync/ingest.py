@@ -4,8 +4,12 @@ The reference opens a cv.VideoCapture and `takePic()` returns what `.read()` yie
 converted on the CPU from what the camera delivers.  A UVC camera delivers packed YUYV 4:2:2; this module takes such
 raw frames from any byte stream (a file of raw frames, a pipe from a capture tool such as `v4l2-ctl --stream-to=-`, a
 V4L2 device node opened for read() I/O) and converts them on the GPU (camsync_ingest_yuyv).  It offers VideoCapture's
-two methods the reference uses, `read()` and `release()`, so it can stand in as `Camera.captureStream`.  Opening camera
-hardware itself (device enumeration, focus and resolution controls, camera.py:102-118) stays outside this package.
+two methods the reference uses, `read()` and `release()`, so it can stand in as `Camera.captureStream`.  Cameras that
+deliver MJPG instead (what VideoCapture negotiates where YUYV is not offered at the resolution asked for) send one
+baseline JPEG per frame: `MJPEGStream` splits such a byte stream into frames and decodes them on the GPU
+(camsync_decode_jpeg_batch), and `imread` decodes a stored JPEG photo the same way (cv.imread of the reference's
+pics/*.jpg).  Opening camera hardware itself (device enumeration, focus and resolution controls, camera.py:102-118)
+stays outside this package.
 """
 import numpy as np
 
@@ -64,3 +68,106 @@ class RawYUYVStream:
             self._f.close()
         self._f = None
         self._pin = None
+
+
+def _jpeg_end(buf, start):
+    """Index one past the EOI marker of the JPEG that starts at buf[start], or -1 if the buffer ends before it.
+    Header segments are skipped by their lengths; in entropy-coded data a 0xFF is followed by 0x00 (a stuffed byte), a
+    restart marker or the marker that ends the scan."""
+    n = len(buf)
+    i = start + 2
+    while True:
+        if i + 2 > n:
+            return -1
+        if buf[i] != 0xFF:
+            raise ValueError("damaged JPEG stream (no marker where one is due)")
+        m = buf[i + 1]
+        if m == 0xFF:
+            i += 1
+            continue
+        if m == 0xD9:
+            return i + 2
+        if m == 0xD8 or m == 0x01 or 0xD0 <= m <= 0xD7:
+            i += 2
+            continue
+        if i + 4 > n:
+            return -1
+        i += 2 + ((buf[i + 2] << 8) | buf[i + 3])
+        if m == 0xDA:  # entropy-coded data up to the next marker that is not a restart marker
+            while True:
+                j = buf.find(b"\xff", i)
+                if j < 0 or j + 1 >= n:
+                    return -1
+                if buf[j + 1] == 0 or 0xD0 <= buf[j + 1] <= 0xD7 or buf[j + 1] == 0xFF:
+                    i = j + (1 if buf[j + 1] == 0xFF else 2)
+                    continue
+                i = j
+                break
+
+
+class MJPEGStream:
+    """VideoCapture-like source of MJPEG frames (concatenated baseline JPEGs, as a UVC camera in MJPG mode or
+    `v4l2-ctl --stream-to=-` delivers them) from a file name or any object with read(n); frames are decoded on the GPU."""
+
+    def __init__(self, source, device=0, chunk=1 << 20):
+        self._own = isinstance(source, (str, bytes))
+        self._f = open(source, "rb") if self._own else source
+        self._device = device
+        self._chunk = chunk
+        self._buf = bytearray()
+
+    def isOpened(self):
+        return self._f is not None
+
+    def _next_frame(self):
+        """The bytes of the next JPEG of the stream, or None at its end."""
+        while self._f is not None:
+            start = self._buf.find(b"\xff\xd8")
+            if start >= 0:
+                end = _jpeg_end(self._buf, start)
+                if end > 0:
+                    frame = bytes(self._buf[start:end])
+                    del self._buf[:end]
+                    return frame
+            more = self._f.read(self._chunk)
+            if not more:
+                return None
+            self._buf += more
+        return None
+
+    def _decode(self, frames):
+        h, w, _ = _hip.jpeg_info(frames[0])
+        ctx = _hip.get_context(max(h, 32), max(w, 32), len(frames), self._device)
+        return ctx.decode_jpeg(frames)
+
+    def read(self):
+        """(True, BGR frame [H,W,3] uint8) or (False, None) at the end of the stream, like cv.VideoCapture.read()."""
+        frame = self._next_frame()
+        if frame is None:
+            return False, None
+        return True, self._decode([frame])[0]
+
+    def read_batch(self, n):
+        """Up to n frames at once (they must be of one size): BGR [k,H,W,3]; the frames are decoded side by side."""
+        frames = []
+        while len(frames) < n:
+            f = self._next_frame()
+            if f is None:
+                break
+            frames.append(f)
+        if not frames:
+            return np.empty((0, 0, 0, 3), np.uint8)
+        return self._decode(frames)
+
+    def release(self):
+        if self._f is not None and self._own:
+            self._f.close()
+        self._f = None
+
+
+def imread(path, device=0):
+    """cv.imread for a baseline JPEG file: BGR [H,W,3] uint8, decoded on the GPU."""
+    with open(path, "rb") as f:
+        data = f.read()
+    h, w, _ = _hip.jpeg_info(data)
+    return _hip.get_context(max(h, 32), max(w, 32), 1, device).decode_jpeg([data])[0]

@@ -43,17 +43,19 @@ struct JpegDesc {         // one frame
     uint8_t pad;
 };
 
-constexpr int kHuffTableBytes = 1024;  // look[256] u16 | maxcode[18] i32 | valoff[17] i32 | huffval[256] u8
+constexpr int kHuffTableBytes = 1024;  // look[256] u16 | limit[18] u32 | valoff[17] i32 | huffval[256] u8
 constexpr int kHuffSetTables = 6;      // DC slots 0..2, AC slots 0..2
-constexpr int kOffMaxcode = 512, kOffValoff = 512 + 72, kOffHuffval = 512 + 72 + 68;
+constexpr int kOffLimit = 512, kOffValoff = 512 + 72, kOffHuffval = 512 + 72 + 68;
 
-__constant__ uint8_t c_zigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
-                                     41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
-                                     30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
-const uint8_t h_zigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
-                              41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
-                              30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
-
+// where the coefficient coded k-th goes in k_jpeg_idct's LDS block (row * 9 + column)
+#define ZZ9(n) (uint8_t)(((n) >> 3) * 9 + ((n) & 7))
+__constant__ __align__(8) uint8_t c_zigzag9[64] = {
+    ZZ9(0),  ZZ9(1),  ZZ9(8),  ZZ9(16), ZZ9(9),  ZZ9(2),  ZZ9(3),  ZZ9(10), ZZ9(17), ZZ9(24), ZZ9(32), ZZ9(25), ZZ9(18),
+    ZZ9(11), ZZ9(4),  ZZ9(5),  ZZ9(12), ZZ9(19), ZZ9(26), ZZ9(33), ZZ9(40), ZZ9(48), ZZ9(41), ZZ9(34), ZZ9(27), ZZ9(20),
+    ZZ9(13), ZZ9(6),  ZZ9(7),  ZZ9(14), ZZ9(21), ZZ9(28), ZZ9(35), ZZ9(42), ZZ9(49), ZZ9(56), ZZ9(57), ZZ9(50), ZZ9(43),
+    ZZ9(36), ZZ9(29), ZZ9(22), ZZ9(15), ZZ9(23), ZZ9(30), ZZ9(37), ZZ9(44), ZZ9(51), ZZ9(58), ZZ9(59), ZZ9(52), ZZ9(45),
+    ZZ9(38), ZZ9(31), ZZ9(39), ZZ9(46), ZZ9(53), ZZ9(60), ZZ9(61), ZZ9(54), ZZ9(47), ZZ9(55), ZZ9(62), ZZ9(63)};
+#undef ZZ9
 __device__ __forceinline__ void wave_lds_order() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -61,161 +63,199 @@ __device__ __forceinline__ void wave_lds_order() {
 }
 
 // ---- entropy decoding ------------------------------------------------------------------------------------------------
-// groups: [nGroups][65] = table set, then 64 frame indices (-1 = none).  status[f]: 0 ok, 1 corrupt entropy data.
+// groups: [nGroups][1 + kHuffLanes] = table set, then the frames of the workgroup's lanes (-1 = none).
+// status[f]: 0 ok, 1 corrupt entropy data.  Coefficients are stored in the order they are coded (zigzag); k_jpeg_idct
+// puts them in place.
+//
+// What the loop is built around: a lane's chain of dependent steps is all there is to hide nothing behind (a few dozen
+// waves on the whole chip), so what matters is what a step waits for.  (1) Global loads and stores share one counter on
+// this chip and a wait for a load also waits for every store issued before it -- with the coefficient stores in the
+// loop, every wait for bitstream bytes became a wait for the previous symbol's store to reach the L2 (1.3 us per
+// symbol).  So the loop never waits for memory: each lane's next kilobyte of bitstream sits in an LDS window, refilled
+// by the whole wave with one coalesced 16-byte load per lane (a wait for memory once per ~1600 symbols of a lane), and
+// the stores are fire-and-forget.  (2) A code longer than the 8-bit look-up finds its length by eight comparisons
+// against left-aligned limits instead of a loop of dependent look-ups; with several lanes per wave some lane needs
+// that path in most steps.  (3) Few frames per wave: the rare paths (byte stuffing, long codes, restart markers,
+// window refills) cost every lane of the wave whenever one lane takes them, and with a wave per SIMD at most there are
+// SIMDs to spare.  2048 1080p frames, ms per batch: 64 frames per wave (and loads from memory) 555, 32: 440, 16: 386,
+// 8: 333, 4: 288, 2: 288.  What is left is the chain itself: ~0.75 us per symbol on a wave that has its SIMD to itself.
+#ifndef HUFF_LANES
+#define HUFF_LANES 4
+#endif
+constexpr int kHuffLanes = HUFF_LANES;  // frames per workgroup (= wavefront)
+constexpr int kHuffWindow = 1024; // bytes of bitstream per lane in LDS
+constexpr int kHuffSlack = 16;    // a step reads at most this far ahead of its position
+
 __global__ __launch_bounds__(64) void k_jpeg_huff(const uint8_t* __restrict__ bytes, const JpegDesc* __restrict__ desc,
                                                   const int32_t* __restrict__ groups, const uint8_t* __restrict__ tableSets,
                                                   int16_t* __restrict__ coef, uint32_t frameBlocks, int32_t* __restrict__ status) {
     __shared__ __align__(16) uint8_t s_tab[kHuffSetTables * kHuffTableBytes];
-    __shared__ uint8_t s_zz[64];
+    __shared__ __align__(16) uint8_t s_win[kHuffLanes][kHuffWindow];
     const int lane = threadIdx.x;
-    const int32_t* grp = groups + (size_t)blockIdx.x * 65;
+    const int32_t* grp = groups + (size_t)blockIdx.x * (1 + kHuffLanes);
     {
         const uint4* src = reinterpret_cast<const uint4*>(tableSets + (size_t)grp[0] * kHuffSetTables * kHuffTableBytes);
         uint4* dst = reinterpret_cast<uint4*>(s_tab);
         for (int i = lane; i < kHuffSetTables * kHuffTableBytes / 16; i += 64) dst[i] = src[i];
-        s_zz[lane] = c_zigzag[lane];
     }
     __syncthreads();
-    const int f = grp[1 + lane];
-    if (f < 0) return;
-    const JpegDesc d = desc[f];
-    const uint8_t* const p = bytes + d.dataOff;
+    const int f = lane < kHuffLanes ? grp[1 + lane] : -1;
+    bool active = f >= 0;
+    JpegDesc d{};
+    if (active) d = desc[f];
     const uint32_t limit = d.dataLen;
-    int16_t* const fcoef = coef + (size_t)f * frameBlocks * 64;
+    int16_t* const fcoef = coef + (size_t)max(f, 0) * frameBlocks * 64;
     const int nc = d.nc;
     // blocks per row of each component's plane, and the plane's first block
     const uint32_t bw0 = (uint32_t)d.mcux * d.hmax, n0 = bw0 * ((uint32_t)d.mcuy * d.vmax), n1 = (uint32_t)d.mcux * d.mcuy;
+    const uint8_t* const win = s_win[lane & (kHuffLanes - 1)];
 
     uint64_t acc = 0;   // unread bits, left-aligned
     int nb = 0;         // how many of them are valid
-    uint32_t ptr = 0;   // next byte to read
+    uint32_t ptr = 0;   // next byte of the stream to read
+    uint32_t wbase = 0xFFFF0000u;  // stream offset of the window's first byte (none loaded yet)
     bool atMarker = false;
     int pred0 = 0, pred1 = 0, pred2 = 0;
     int c = 0, bx = 0, by = 0, k = 0;
     uint32_t mx = 0, my = 0;
     int toRestart = d.restart, nextRst = 0;
-    bool bad = false;
     uint32_t block = 0;  // the current block's first coefficient
-    bool active = true;
 
-    while (active) {
-        // ---- at least 33 valid bits: a code (<= 16 bits) and its value (<= 16 bits) ----
-        if (nb <= 32) {
-            if (atMarker) {
-                nb = 64;  // (zeros, as jdhuff.c feeds after a marker)
-            } else {
-                uint32_t w = 0;
-                bool fast = ptr + 4 <= limit;
-                if (fast) {
-                    __builtin_memcpy(&w, p + ptr, 4);
-                    const uint32_t t = ~w;  // a zero byte of t is an 0xFF byte of w
-                    fast = ((t - 0x01010101u) & ~t & 0x80808080u) == 0;
-                }
-                if (fast) {
-                    acc |= (uint64_t)__builtin_bswap32(w) << (32 - nb);
-                    nb += 32;
-                    ptr += 4;
+    for (;;) {
+        // ---- windows: every lane's next kHuffSlack bytes are in LDS (refilled by the whole wave, one lane at a time) ----
+        unsigned long long need = __ballot(active && (ptr - wbase > (uint32_t)(kHuffWindow - kHuffSlack)));
+        if (need) {
+            while (need) {
+                const int L = __ffsll((long long)need) - 1;
+                need &= need - 1;
+                const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)(ptr & ~15u), L);
+                const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)d.dataOff, L);
+                // (the byte buffer is padded by more than a window, so the load never leaves it)
+                const uint4 v = *reinterpret_cast<const uint4*>(bytes + (size_t)off + base + (size_t)lane * 16);
+                *reinterpret_cast<uint4*>(&s_win[L][lane * 16]) = v;
+                if (lane == L) wbase = base;
+            }
+            wave_lds_order();
+        }
+        if (!__any(active)) break;
+        if (active) {
+            // ---- at least 33 valid bits: a code (<= 16 bits) and its value (<= 16 bits) ----
+            if (nb <= 32) {
+                if (atMarker) {
+                    nb = 64;  // (zeros, as jdhuff.c feeds after a marker)
                 } else {
-                    while (nb <= 56) {
-                        if (ptr >= limit) { atMarker = true; break; }
-                        uint32_t b = p[ptr];
-                        if (b == 0xFF) {
-                            const uint32_t nx = ptr + 1 < limit ? p[ptr + 1] : 0xD9u;
-                            if (nx != 0) { atMarker = true; break; }
-                            ptr += 2;  // a stuffed zero
-                        } else {
-                            ptr++;
+                    const uint32_t rel = ptr - wbase;
+                    const uint32_t* w32 = reinterpret_cast<const uint32_t*>(win) + (rel >> 2);
+                    const uint32_t w = __builtin_amdgcn_alignbyte(w32[1], w32[0], rel & 3u);  // the four bytes at ptr
+                    const uint32_t t = ~w;  // a zero byte of t is an 0xFF byte of w
+                    if (ptr + 4 <= limit && ((t - 0x01010101u) & ~t & 0x80808080u) == 0) {
+                        acc |= (uint64_t)__builtin_bswap32(w) << (32 - nb);
+                        nb += 32;
+                        ptr += 4;
+                    } else {
+                        uint32_t r = rel;
+                        while (nb <= 56) {
+                            if (ptr >= limit) { atMarker = true; break; }
+                            const uint32_t b = win[r];
+                            if (b == 0xFF) {
+                                const uint32_t nx = ptr + 1 < limit ? win[r + 1] : 0xD9u;
+                                if (nx != 0) { atMarker = true; break; }
+                                ptr += 2;  // a stuffed zero
+                                r += 2;
+                            } else {
+                                ptr++;
+                                r++;
+                            }
+                            acc |= (uint64_t)b << (56 - nb);
+                            nb += 8;
                         }
-                        acc |= (uint64_t)b << (56 - nb);
-                        nb += 8;
+                        if (atMarker) nb = 64;
                     }
-                    if (atMarker) nb = 64;
                 }
             }
-        }
-        // ---- one symbol ----
-        const int slot = k == 0 ? (c == 0 ? d.td[0] : c == 1 ? d.td[1] : d.td[2]) : 3 + (c == 0 ? d.ta[0] : c == 1 ? d.ta[1] : d.ta[2]);
-        const uint8_t* const T = s_tab + slot * kHuffTableBytes;
-        const uint32_t e = reinterpret_cast<const uint16_t*>(T)[(uint32_t)(acc >> 56)];
-        int l, sym;
-        if (e) {
-            l = (int)(e >> 8);
-            sym = (int)(e & 255u);
-        } else {
-            const int32_t* maxcode = reinterpret_cast<const int32_t*>(T + kOffMaxcode);
-            l = 9;
-            while (l <= 16 && (int32_t)(acc >> (64 - l)) > maxcode[l]) l++;
-            if (l > 16) {
-                bad = true;
-                l = 16;
-                sym = 0;
-            } else {
+            // ---- one symbol ----
+            bool bad = false;
+            const int slot = k == 0 ? (c == 0 ? d.td[0] : c == 1 ? d.td[1] : d.td[2]) : 3 + (c == 0 ? d.ta[0] : c == 1 ? d.ta[1] : d.ta[2]);
+            const uint8_t* const T = s_tab + slot * kHuffTableBytes;
+            const uint32_t e = reinterpret_cast<const uint16_t*>(T)[(uint32_t)(acc >> 56)];
+            int l = (int)(e >> 8), sym = (int)(e & 255u);
+            if (!e) {
+                // longer than 8 bits: the code's length is 9 + the number of lengths whose left-aligned limit it reaches
+                const uint32_t* lim = reinterpret_cast<const uint32_t*>(T + kOffLimit);
+                const uint32_t code16 = (uint32_t)(acc >> 48);
+                l = 9;
+#pragma unroll
+                for (int j = 9; j <= 15; j++) l += code16 >= lim[j] ? 1 : 0;
+                bad = code16 >= lim[16];
                 const int32_t* valoff = reinterpret_cast<const int32_t*>(T + kOffValoff);
-                sym = T[kOffHuffval + (((int32_t)(acc >> (64 - l)) + valoff[l]) & 255)];
+                sym = T[kOffHuffval + (((int32_t)(code16 >> (16 - l)) + valoff[l]) & 255)];
             }
-        }
-        acc <<= l;
-        nb -= l;
-        const int s = k == 0 ? sym : (sym & 15);
-        int val = 0;
-        if (s) {
-            const int sl = min(s, 16);
-            const int r = (int)(acc >> (64 - sl));
-            acc <<= sl;
-            nb -= sl;
-            val = r < (1 << (sl - 1)) ? r - (1 << sl) + 1 : r;
-        }
-        if (k == 0) {
-            if (sym > 16) bad = true;
-            int pr = c == 0 ? pred0 : c == 1 ? pred1 : pred2;
-            pr += val;
-            if (c == 0) pred0 = pr; else if (c == 1) pred1 = pr; else pred2 = pr;
-            // the block this DC coefficient starts
-            const uint32_t bwc = c == 0 ? bw0 : (uint32_t)d.mcux;
-            const uint32_t row = c == 0 ? my * d.vmax + (uint32_t)by : my, col = c == 0 ? mx * d.hmax + (uint32_t)bx : mx;
-            block = ((c == 0 ? 0u : c == 1 ? n0 : n0 + n1) + row * bwc + col) * 64u;
-            fcoef[block] = (int16_t)pr;
-            k = 1;
-        } else {
-            const int r = sym >> 4;
+            acc <<= l;
+            nb -= l;
+            const int s = k == 0 ? sym : (sym & 15);
+            int val = 0;
             if (s) {
-                k += r;
-                if (k > 63) { bad = true; k = 64; }
-                else { fcoef[block + s_zz[k]] = (int16_t)val; k++; }
-            } else {
-                k = r == 15 ? k + 16 : 64;
+                const int sl = min(s, 16);
+                const int r = (int)(acc >> (64 - sl));
+                acc <<= sl;
+                nb -= sl;
+                val = r < (1 << (sl - 1)) ? r - (1 << sl) + 1 : r;
             }
-        }
-        if (bad) {
-            status[f] = 1;
-            active = false;
-        } else if (k >= 64) {
-            // ---- next block, MCU, restart interval ----
-            k = 0;
-            const int hc = c == 0 ? d.hmax : 1, vc = c == 0 ? d.vmax : 1;
-            if (++bx == hc) {
-                bx = 0;
-                if (++by == vc) {
-                    by = 0;
-                    if (++c == nc) {
-                        c = 0;
-                        if (++mx == d.mcux) { mx = 0; my++; }
-                        if (my == d.mcuy) {
-                            active = false;
-                        } else if (d.restart && --toRestart == 0) {
-                            // the bits left are the padding of the interval's last byte; the marker follows (after fill bytes)
-                            acc = 0;
-                            nb = 0;
-                            while (ptr + 1 < limit && p[ptr] == 0xFF && p[ptr + 1] == 0xFF) ptr++;
-                            if (ptr + 1 < limit && p[ptr] == 0xFF && p[ptr + 1] == (uint32_t)(0xD0 + nextRst)) {
-                                ptr += 2;
-                                atMarker = false;
-                                nextRst = (nextRst + 1) & 7;
-                                pred0 = pred1 = pred2 = 0;
-                                toRestart = d.restart;
-                            } else {
-                                status[f] = 1;
+            if (k == 0) {
+                if (sym > 16) bad = true;
+                int pr = c == 0 ? pred0 : c == 1 ? pred1 : pred2;
+                pr += val;
+                if (c == 0) pred0 = pr; else if (c == 1) pred1 = pr; else pred2 = pr;
+                // the block this DC coefficient starts
+                const uint32_t bwc = c == 0 ? bw0 : (uint32_t)d.mcux;
+                const uint32_t row = c == 0 ? my * d.vmax + (uint32_t)by : my, col = c == 0 ? mx * d.hmax + (uint32_t)bx : mx;
+                block = ((c == 0 ? 0u : c == 1 ? n0 : n0 + n1) + row * bwc + col) * 64u;
+                if (!bad) fcoef[block] = (int16_t)pr;
+                k = 1;
+            } else {
+                const int r = sym >> 4;
+                if (s) {
+                    k += r;
+                    if (k > 63) bad = true;
+                    else fcoef[block + (uint32_t)k] = (int16_t)val;
+                    k++;
+                } else {
+                    k = r == 15 ? k + 16 : 64;
+                }
+            }
+            if (bad) {
+                status[f] = 1;
+                active = false;
+            } else if (k >= 64) {
+                // ---- next block, MCU, restart interval ----
+                k = 0;
+                const int hc = c == 0 ? d.hmax : 1, vc = c == 0 ? d.vmax : 1;
+                if (++bx == hc) {
+                    bx = 0;
+                    if (++by == vc) {
+                        by = 0;
+                        if (++c == nc) {
+                            c = 0;
+                            if (++mx == d.mcux) { mx = 0; my++; }
+                            if (my == d.mcuy) {
                                 active = false;
+                            } else if (d.restart && --toRestart == 0) {
+                                // the bits left are the padding of the interval's last byte; the marker follows (after
+                                // fill bytes).  Rare: read from memory.
+                                const uint8_t* const p = bytes + d.dataOff;
+                                acc = 0;
+                                nb = 0;
+                                while (ptr + 1 < limit && p[ptr] == 0xFF && p[ptr + 1] == 0xFF) ptr++;
+                                if (ptr + 1 < limit && p[ptr] == 0xFF && p[ptr + 1] == (uint32_t)(0xD0 + nextRst)) {
+                                    ptr += 2;
+                                    atMarker = false;
+                                    nextRst = (nextRst + 1) & 7;
+                                    pred0 = pred1 = pred2 = 0;
+                                    toRestart = d.restart;
+                                } else {
+                                    status[f] = 1;
+                                    active = false;
+                                }
                             }
                         }
                     }
@@ -285,10 +325,13 @@ __global__ __launch_bounds__(256) void k_jpeg_idct(int16_t* __restrict__ coef, c
     const uint4 qv = *reinterpret_cast<const uint4*>(quant + ((size_t)f * 4 + (c == 0 ? d.tq[0] : c == 1 ? d.tq[1] : d.tq[2])) * 64 + r * 8);
     const uint32_t cw[4] = {cv.x, cv.y, cv.z, cv.w}, qw[4] = {qv.x, qv.y, qv.z, qv.w};
     int32_t* const ws = s_ws[g];
+    // this lane holds the coefficients coded 8 r-th .. 8 r + 7-th and their quantisation steps (both in coding order)
+    const uint2 zz = *reinterpret_cast<const uint2*>(&c_zigzag9[r * 8]);
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        ws[r * 9 + 2 * i] = jmul((int32_t)(int16_t)(cw[i] & 0xFFFFu), (int32_t)(qw[i] & 0xFFFFu));
-        ws[r * 9 + 2 * i + 1] = jmul((int32_t)(int16_t)(cw[i] >> 16), (int32_t)(qw[i] >> 16));
+        const uint32_t z = i < 2 ? zz.x >> (16 * i) : zz.y >> (16 * (i - 2));
+        ws[z & 255u] = jmul((int32_t)(int16_t)(cw[i] & 0xFFFFu), (int32_t)(qw[i] & 0xFFFFu));
+        ws[(z >> 8) & 255u] = jmul((int32_t)(int16_t)(cw[i] >> 16), (int32_t)(qw[i] >> 16));
     }
     wave_lds_order();
     int32_t in[8], out[8];
@@ -427,10 +470,11 @@ struct HuffSpec {  // a DHT table as the file gives it
 bool build_table(const HuffSpec& h, uint8_t* out) {
     memset(out, 0, kHuffTableBytes);
     uint16_t* look = reinterpret_cast<uint16_t*>(out);
-    int32_t* maxcode = reinterpret_cast<int32_t*>(out + kOffMaxcode);
+    uint32_t* limit = reinterpret_cast<uint32_t*>(out + kOffLimit);  // [l]: first 16-bit left-aligned code that is longer than l bits
     int32_t* valoff = reinterpret_cast<int32_t*>(out + kOffValoff);
     memcpy(out + kOffHuffval, h.vals, (size_t)h.total);
     int code = 0, p = 0;
+    limit[0] = 0;
     for (int l = 1; l <= 16; l++) {
         const int n = h.bits[l - 1];
         if (n) {
@@ -440,20 +484,17 @@ bool build_table(const HuffSpec& h, uint8_t* out) {
                     for (int j = 0; j < (1 << (8 - l)); j++) look[((code + i) << (8 - l)) + j] = (uint16_t)((l << 8) | h.vals[p + i]);
             p += n;
             code += n;
-            maxcode[l] = code - 1;
-        } else {
-            maxcode[l] = -1;
         }
         if (code > (1 << l)) return false;
+        limit[l] = (uint32_t)code << (16 - l);
         code <<= 1;
     }
-    maxcode[17] = 0x7FFFFFFF;
     return true;
 }
 
 struct ParsedFrame {
     JpegDesc d{};
-    uint16_t quant[4][64];
+    uint16_t quant[4][64];  // in coding (zigzag) order, as the file has them
     size_t scanOff = 0;  // first entropy-coded byte in the file
     HuffSpec dc[3], ac[3];  // by slot
 };
@@ -483,7 +524,7 @@ const char* parse_frame(const uint8_t* data, size_t n, int H, int W, ParsedFrame
                 const int pq = s[k] >> 4, tq = s[k] & 15;
                 if (tq > 3 || pq > 1 || k + 1 + (pq ? 128u : 64u) > len) return "bad quantisation table";
                 for (int j = 0; j < 64; j++)
-                    out.quant[tq][h_zigzag[j]] = pq ? (uint16_t)((s[k + 1 + 2 * j] << 8) | s[k + 2 + 2 * j]) : s[k + 1 + j];
+                    out.quant[tq][j] = pq ? (uint16_t)((s[k + 1 + 2 * j] << 8) | s[k + 2 + 2 * j]) : s[k + 1 + j];
                 qset[tq] = true;
                 k += 1 + (pq ? 128 : 64);
             }
@@ -660,7 +701,7 @@ int jpeg_decode_batch(JpegState* s, hipStream_t st, const uint8_t* const* jpegs,
             totalBytes += (pf[(size_t)i].d.dataLen + 15u) & ~(size_t)15u;
             if (totalBytes > 0xFFFF0000ull) { err = "more than 4 GiB of compressed data in one pass"; return CAMSYNC_E_ARG; }
         }
-        totalBytes += 16;  // (the bit reader fetches four bytes at a time)
+        totalBytes += kHuffWindow + 64;  // (a lane's window is loaded whole, wherever its stream ends)
         // blocks per frame of this pass: the largest of its frames' layouts
         uint32_t frameBlocks = 0;
         for (int i = 0; i < nb; i++) {
@@ -692,11 +733,11 @@ int jpeg_decode_batch(JpegState* s, hipStream_t st, const uint8_t* const* jpegs,
         }
         groups.clear();
         for (size_t set = 0; set < framesOfSet.size(); set++)
-            for (size_t k = 0; k < framesOfSet[set].size(); k += 64) {
+            for (size_t k = 0; k < framesOfSet[set].size(); k += kHuffLanes) {
                 groups.push_back((int32_t)set);
-                for (size_t j = 0; j < 64; j++) groups.push_back(k + j < framesOfSet[set].size() ? framesOfSet[set][k + j] : -1);
+                for (size_t j = 0; j < (size_t)kHuffLanes; j++) groups.push_back(k + j < framesOfSet[set].size() ? framesOfSet[set][k + j] : -1);
             }
-        const int nGroups = (int)(groups.size() / 65);
+        const int nGroups = (int)(groups.size() / (1 + kHuffLanes));
         descs.resize((size_t)nb);
         quant.resize((size_t)nb * 256);
         for (int i = 0; i < nb; i++) {

@@ -161,3 +161,28 @@ def test_gpu_refuses_what_the_decoder_does_not_take():
     except _hip.CamsyncError as e2:
         assert e2.code == _hip.E_ARG
     assert np.array_equal(ctx.decode_jpeg([good])[0], orc.jpeg_decode(good))
+
+
+@pytest.mark.gpu
+def test_camera_takes_pictures_from_an_mjpeg_stream():
+    """The mirror's Camera over a stream of MJPEG frames (what a camera in MJPG mode sends): takePic() yields the frames
+    cv.VideoCapture.read() would (reference camera.py:150-154), here the reference's own photos of the marker sheet,
+    and they carry the oracle's detections."""
+    from cameracalibration_amd.camera_sync.camera import Camera
+    from cameracalibration_amd.camera_sync.ingest import MJPEGStream, imread
+    from cameracalibration_amd.camera_sync.aruco import detectAruco
+    files = _reference_jpegs()[9:17]  # pics/poses
+    stream = io.BytesIO(b"".join(b"\x00junk" + open(f, "rb").read() for f in files))  # (bytes between frames are skipped)
+    cam = Camera("mjpeg", -1, captureStream=MJPEGStream(stream, chunk=4096))
+    for f in files[:3]:
+        frame = cam.takePic()
+        want = orc.jpeg_decode(open(f, "rb").read())
+        assert np.array_equal(frame, want)
+        assert np.array_equal(imread(f), want)
+    arucos = detectAruco(frame)[0]
+    oi, _, _ = orc.detect(want)
+    assert sorted(arucos.keys()) == sorted(oi.tolist()) and len(oi) >= 4
+    rest = cam.captureStream.read_batch(16)
+    assert rest.shape == (5, 480, 640, 3)
+    assert np.array_equal(rest[4], orc.jpeg_decode(open(files[7], "rb").read()))
+    assert cam.takePic() is False
