@@ -2,10 +2,10 @@
 
 On the hot path a Camera is the holder of the intrinsics (`mtx`, `dist`, loaded from
 calibration/<name>_<w>-<h>_<focus>.npz) and of the stateful world pose
-(`world2cam`, low-passed `world_position`).  Opening camera hardware (cv.VideoCapture(deviceId)) is outside
-the scope of this package: a Camera takes a `captureStream` object instead (anything with VideoCapture's
-`read()`, e.g. `ingest.RawYUYVStream`, which converts a camera's raw YUYV frames on the GPU); image undistortion
-and the LM solve behind cv.calibrateCamera run on the GPU.
+(`world2cam`, low-passed `world_position`).  A camera device is opened through V4L2 (`v4l2.V4L2Capture`, the
+stand-in for cv.VideoCapture(deviceId): raw YUYV or MJPG frames, converted on the GPU), or the Camera takes a
+`captureStream` object (anything with VideoCapture's `read()`, e.g. `ingest.RawYUYVStream` / `ingest.MJPEGStream`
+over a file or a pipe); image undistortion and the LM solve behind cv.calibrateCamera run on the GPU.
 """
 import os
 
@@ -110,9 +110,14 @@ class Camera:
         self.calibrationFolder = calibrationFolder
         self.name = name
         if deviceId != -1 and captureStream is None:
-            # camera.py:98-118 opens a cv.VideoCapture(deviceId) here and sets its focus and resolution
-            raise NotImplementedError("opening camera hardware is outside this package's scope: pass captureStream= "
-                                      "(e.g. ingest.RawYUYVStream) or use deviceId=-1 and pass frames in")
+            # camera.py:98-118: open the capture device, autofocus off, focus from 0..100 to 0..255 in steps of 5, frame
+            # size.  (V4L2 on Linux; a device that cannot be opened yields no frames, as with cv.VideoCapture.)
+            from .v4l2 import CAP_PROP_AUTOFOCUS, CAP_PROP_FOCUS, CAP_PROP_FRAME_HEIGHT, CAP_PROP_FRAME_WIDTH, V4L2Capture
+            captureStream = V4L2Capture(deviceId)
+            captureStream.set(CAP_PROP_AUTOFOCUS, 0)
+            captureStream.set(CAP_PROP_FOCUS, round(max(0, min(100, focus)) * 255 / 100 / 5) * 5)
+            captureStream.set(CAP_PROP_FRAME_WIDTH, resolution[0])
+            captureStream.set(CAP_PROP_FRAME_HEIGHT, resolution[1])
         self.deviceId = deviceId
         self.captureStream = captureStream
         self.world_position = Position(0, 0, 0)
@@ -148,7 +153,7 @@ class Camera:
     def takePic(self):
         """camera.py:150-154: the next frame of the capture stream, or False when it yields none."""
         if self.captureStream is None:
-            raise NotImplementedError("this Camera has no captureStream (opening camera hardware is outside this package's scope)")
+            raise NotImplementedError("this Camera has no captureStream (deviceId -1: frames are passed in)")
         ret, frame = self.captureStream.read()
         if ret:
             return frame

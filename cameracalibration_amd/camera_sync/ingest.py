@@ -8,8 +8,7 @@ two methods the reference uses, `read()` and `release()`, so it can stand in as 
 deliver MJPG instead (what VideoCapture negotiates where YUYV is not offered at the resolution asked for) send one
 baseline JPEG per frame: `MJPEGStream` splits such a byte stream into frames and decodes them on the GPU
 (camsync_decode_jpeg_batch), and `imread` decodes a stored JPEG photo the same way (cv.imread of the reference's
-pics/*.jpg).  Opening camera hardware itself (device enumeration, focus and resolution controls, camera.py:102-118)
-stays outside this package.
+pics/*.jpg).  The camera device itself is opened by `v4l2.V4L2Capture` (camera.py:102-118), which feeds the same two conversions.
 """
 import numpy as np
 

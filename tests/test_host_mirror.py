@@ -139,6 +139,6 @@ def test_camera_loads_calibration_and_tracks_pose(capsys):
     assert not none.calibrated
     with pytest.raises(Exception, match="Calibration folder not found"):
         Camera("x", -1, calibrationFolder="/nonexistent/folder")
-    with pytest.raises(NotImplementedError):
-        Camera("Logitec_A", 0)
+    absent = Camera("Logitec_A", 62)  # no such camera here: like cv.VideoCapture, no exception and no frames
+    assert not absent.captureStream.isOpened() and absent.takePic() is False
     assert np.array_equal(Camera.boardPoints((7, 7))[:3], [[0, 0, 0], [1, 0, 0], [2, 0, 0]])
