@@ -909,14 +909,15 @@ __device__ __forceinline__ bool seed_supported(uint32_t m, int dir) {
 // row 0 repeats row 16, row 17 repeats row 1), so one address and two immediate offsets fetch the three rows; the two
 // words of a row are read by the word the neighbourhood starts in and the other one (address ^ 4), which a funnel shift
 // joins.  Steps per service phase, border stage of the bench scene / the photo scene in ms: 4: 4.29 / 8.15, 6: 4.16 /
-// 7.84, 8: 4.04 / 7.66 (more does not fit the 32-bit group of chain codes).
+// 7.84, 8: 4.04 / 7.66, 12: 3.95 / 7.41, 16: 3.98 / 7.41 (a group's chain codes are one 64-bit word; with more steps
+// between two phases more lanes stand at the edge of their window waiting for the next one).
 constexpr int kWin2Rows = kWinRows + 2;
 constexpr int kTile2Words = kWin2Rows * 2 * 64;  // per wavefront
 #ifndef WALK2_STEPS
-#define WALK2_STEPS 8
+#define WALK2_STEPS 12
 #endif
 constexpr int kWalk2Steps = WALK2_STEPS;        // steps between two service phases
-static_assert(kWalk2Steps >= 2 && kWalk2Steps <= 8, "a group's chain codes are one 32-bit word");
+static_assert(kWalk2Steps >= 2 && kWalk2Steps <= 16, "a group's chain codes are one 64-bit word");
 constexpr int kWalk2Waves = 5;                  // wavefronts per workgroup (they share the step table): 53 KB of LDS, three workgroups per CU
 
 struct TileWin2 {
@@ -1038,9 +1039,10 @@ __device__ __forceinline__ void seg_walk_lean(const uint32_t* __restrict__ plane
     bool exhausted = false;
     uint32_t id = 0, count = 0, total = 0, minAll = 0xFFFFFFFFu, minEast = 0xFFFFFFFFu, startPix = 0, state0 = 0;
     uint32_t endNext = kSegNone, endKey = 0;
-    // chain codes: grp = the (up to four) steps since the last service phase, 4 bits each from bit 0; acc = the steps
+    // chain codes: grp = the (up to kWalk2Steps) steps since the last service phase, 4 bits each from bit 0; acc = the steps
     // before them that have not filled a word yet, flushed = steps of this segment already written or in acc's words
-    uint32_t grp = 0, count0 = 0;
+    uint64_t grp = 0;
+    uint32_t count0 = 0;
     uint64_t acc = 0;
     int startKey = 0, cx = 1, cy = 1, s = 0;
     const uint32_t* plane = planes;
@@ -1057,10 +1059,18 @@ __device__ __forceinline__ void seg_walk_lean(const uint32_t* __restrict__ plane
         {
             const uint32_t e = count - count0;          // steps of the group (0..kWalk2Steps)
             const uint32_t at = count0 & 7u;            // their place in the word being filled
-            acc |= (uint64_t)grp << (4u * at);
-            if (at + e >= 8u) {                         // the word is full
+            // (acc holds `at` codes; with the group's up to sixteen that is up to 92 bits: `over` takes what leaves acc)
+            const uint64_t over = (kWalk2Steps > 8 && at) ? grp >> (64u - 4u * at) : 0ull;
+            acc |= grp << (4u * at);
+            const uint32_t full = (at + e) >> 3;        // words that are full now
+            if (full >= 1u) {
                 chain[(size_t)id * 32 + ((count0 >> 3) & 31u)] = (uint32_t)acc;
-                acc >>= 32;
+                if (kWalk2Steps > 8 && full >= 2u) {
+                    chain[(size_t)id * 32 + (((count0 >> 3) + 1u) & 31u)] = (uint32_t)(acc >> 32);
+                    acc = over;
+                } else {
+                    acc = (acc >> 32) | (over << 32);
+                }
             }
             grp = 0;
             count0 = count;
@@ -1187,7 +1197,7 @@ __device__ __forceinline__ void seg_walk_lean(const uint32_t* __restrict__ plane
                 const uint32_t eastHere = emit ? east : (f >> 1);
                 minEast = min(minEast, eastHere ? key : 0xFFFFFFFFu);
                 minAll = min(minAll, emit ? key : 0xFFFFFFFFu);
-                grp |= emit ? q << (4 * k) : 0u;
+                grp |= emit ? (uint64_t)q << (4 * k) : 0ull;
                 count += emit ? 1u : 0u;
                 cx += (int)((L >> 12) & 3u) - 1;   // (a lane that stops does not look at its position again)
                 cy += (int)((L >> 14) & 3u) - 1;
