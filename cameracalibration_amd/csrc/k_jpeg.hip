@@ -3,20 +3,21 @@
 // them to the reference (camera_sync/camera.py:98-118, 150-154; both end in libjpeg-turbo with its defaults:
 // accurate integer IDCT, triangle-filter chroma upsampling, 16-bit fixed-point YCbCr -> RGB).
 //
-// Three kernels per batch:
-//   k_jpeg_huff   entropy decoding (ITU T.81 Annex F).  A frame's Huffman stream is sequential, so the parallelism is
-//                 the batch: one lane per frame, the 64 frames of a workgroup share their Huffman tables in LDS (the
-//                 host groups frames by table set: the frames of one camera all use one).  Every lane decodes one
-//                 symbol per iteration whatever block or coefficient it is at (a flat state machine: no lane waits
-//                 for another's block to end) and stores the coefficient straight into the frame's coefficient
-//                 planes, which are all zero between calls.
+// Three stages per batch:
+//   k_jpeg_huff_wave, k_jpeg_huff   entropy decoding (ITU T.81 Annex F).  A frame's Huffman stream is sequential.
+//                 k_jpeg_huff_wave gives a frame a wavefront: every lane decodes the symbol that would start at its
+//                 bit offset of a 64-bit window, the real symbols are the chain from offset 0 (see the kernel).
+//                 k_jpeg_huff (frames with more than two Huffman tables of a class) gives a frame a lane, a few
+//                 frames of one table set to a wavefront, one symbol per iteration whatever block or coefficient a
+//                 lane is at.  Both store the coefficients straight into the frame's coefficient planes, in coding
+//                 order; the planes are all zero between calls.
 //   k_jpeg_idct   dequantisation + inverse DCT (jidctint.c's two passes, 32-bit) of every block: eight lanes per block,
 //                 a row of coefficients each (coalesced 16-byte loads), transposed through LDS for the column pass;
 //                 writes the component planes and puts the zeros back into the coefficient planes.
 //   k_jpeg_color  chroma upsampling (h2v1 / h2v2 triangle filters, or none) + colour conversion + BGR packing, four
 //                 pixels per lane.
-// Bound: the Huffman kernel by the latency of one lane's dependent chain (≈ 70 instructions per symbol), the other two
-// by HBM (128 B + 128 B + 64 B per block; 1.5-3 B + 3 B per pixel).
+// Bound: the Huffman kernels by the chain of dependent steps from one symbol to the next (≈ 350 cycles per symbol with a
+// wavefront per frame), the other two by HBM (128 B + 128 B + 64 B per block; 1.5-3 B + 3 B per pixel).
 //
 // Scope (the host parser refuses the rest with CAMSYNC_E_ARG): SOF0 / SOF1, 8-bit, one interleaved scan, 1 or 3
 // components (Y / YCbCr), luma sampling 1x1, 2x1 or 2x2 with 1x1 chroma, restart intervals, frames without DHT
@@ -263,6 +264,234 @@ __global__ __launch_bounds__(64) void k_jpeg_huff(const uint8_t* __restrict__ by
             }
         }
     }
+}
+
+// ---- entropy decoding, one wavefront per frame ------------------------------------------------------------------------
+// A lane per frame leaves a frame to one lane's chain of dependent steps: a quarter of a second for a 1080p frame, which
+// is what a caller pays who decodes one frame at a time (Camera.takePic over an MJPG camera).  Here a wavefront takes a
+// frame: every lane decodes the symbol that WOULD start at its own bit offset of a 64-bit window (look-up, long codes,
+// value bits -- everything that costs instructions -- for each of the tables a symbol there could use), then the
+// symbols that really are there are found by following the chain of lengths from offset 0, ~30 scalar instructions per
+// symbol (v_readlane), and the lanes on the chain store their coefficients together.  ~10 symbols per window.
+// One 1080p frame of 236 KB: 73 ms (a lane per frame: 240 ms); 4096 of them: 282 ms (378 ms).  All four tables are
+// worked out for every window: computing a DC table or the second AC table only when the chain gets to a block that
+// needs it saved instructions and was slower (79 ms), because the look-ups of the four then wait one after the other.
+// The bitstream is unstuffed into an LDS ring first (0xFF 0x00 -> 0xFF; the ring ends at a marker, zeros after it as
+// jdhuff.c feeds them), so that bit offsets are plain arithmetic.  Frames with more than two DC or two AC tables go to
+// k_jpeg_huff.
+constexpr int kRingBytes = 2048;       // unstuffed bytes in LDS (a power of two)
+constexpr int kRefillBytes = 256;      // raw bytes per refill: four per lane
+constexpr int kRingNeed = 24;          // bytes a window needs ahead of its first bit (63 + 32 bits, whole words)
+
+// symbol that starts at the top of w (32 bits of the stream) under table T: bits consumed | run << 6 | (size == 0) << 10 |
+// bad << 11 | value << 16.  lim = the table's limits for lengths 9..16 (uniform).
+__device__ __forceinline__ uint32_t huff_symbol(const uint8_t* T, const uint32_t* lim, uint32_t w, bool isDC) {
+    const uint32_t e = reinterpret_cast<const uint16_t*>(T)[w >> 24];
+    const uint32_t code16 = w >> 16;
+    uint32_t ll = 9;
+#pragma unroll
+    for (int j = 0; j < 7; j++) ll += code16 >= lim[j] ? 1u : 0u;
+    const bool bad = !e && code16 >= lim[7];
+    const int32_t* valoff = reinterpret_cast<const int32_t*>(T + kOffValoff);
+    const uint32_t lsym = T[kOffHuffval + (((int32_t)(code16 >> (16u - ll)) + valoff[ll]) & 255)];
+    const uint32_t l = e ? e >> 8 : ll, sym = e ? e & 255u : lsym;
+    const uint32_t size = isDC ? min(sym, 16u) : (sym & 15u), run = isDC ? 0u : sym >> 4;
+    const uint32_t vb = size ? (w << l) >> (32u - size) : 0u;
+    const int val = size && vb < (1u << (size - 1u)) ? (int)vb - (int)(1u << size) + 1 : (int)vb;
+    return (l + size) | (run << 6) | ((size == 0u ? 1u : 0u) << 10) | (((bad || (isDC && sym > 16u)) ? 1u : 0u) << 11) | ((uint32_t)val << 16);
+}
+
+// list: [n][2] = frame, table set
+__global__ __launch_bounds__(64) void k_jpeg_huff_wave(const uint8_t* __restrict__ bytes, const JpegDesc* __restrict__ desc,
+                                                       const int32_t* __restrict__ list, const uint8_t* __restrict__ tableSets,
+                                                       int16_t* __restrict__ coef, uint32_t frameBlocks, int32_t* __restrict__ status) {
+    __shared__ __align__(16) uint8_t s_tab[4 * kHuffTableBytes];  // DC slots 0, 1, AC slots 0, 1
+    __shared__ __align__(16) uint32_t s_ring[kRingBytes / 4];
+    const int lane = threadIdx.x;
+    const int f = list[2 * blockIdx.x];
+    {
+        const uint8_t* set = tableSets + (size_t)list[2 * blockIdx.x + 1] * kHuffSetTables * kHuffTableBytes;
+        uint4* dst = reinterpret_cast<uint4*>(s_tab);
+        for (int i = lane; i < 4 * kHuffTableBytes / 16; i += 64) {
+            const int t = i / (kHuffTableBytes / 16), r = i - t * (kHuffTableBytes / 16);
+            dst[i] = reinterpret_cast<const uint4*>(set + (size_t)(t < 2 ? t : t + 1) * kHuffTableBytes)[r];  // set: DC 0..2, AC 0..2
+        }
+    }
+    __syncthreads();
+    const JpegDesc d = desc[f];
+    const uint8_t* const p = bytes + d.dataOff;
+    const uint32_t limit = d.dataLen;
+    int16_t* const fcoef = coef + (size_t)f * frameBlocks * 64;
+    // the limits of lengths 9..16 of the four tables (uniform)
+    uint32_t lim[4][8];
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            lim[t][j] = (uint32_t)__builtin_amdgcn_readfirstlane((int)reinterpret_cast<const uint32_t*>(s_tab + t * kHuffTableBytes + kOffLimit)[9 + j]);
+    const uint32_t bw0 = (uint32_t)d.mcux * d.hmax, n0 = bw0 * ((uint32_t)d.mcuy * d.vmax), n1 = (uint32_t)d.mcux * d.mcuy;
+    uint8_t* const ring8 = reinterpret_cast<uint8_t*>(s_ring);
+
+    // all of this is the same in every lane
+    uint32_t P = 0;        // bit position in the unstuffed stream (of the current restart interval)
+    uint32_t wp = 0;       // unstuffed bytes in the ring so far
+    uint32_t rp = 0;       // raw bytes consumed
+    uint32_t prevByte = 0; // the raw byte before rp
+    bool atMarker = false;
+    int pred0 = 0, pred1 = 0, pred2 = 0;
+    int c = 0, bx = 0, by = 0, k = 0;
+    uint32_t mx = 0, my = 0, block = 0;
+    int toRestart = d.restart, nextRst = 0;
+    bool done = false, bad = false, restartNow = false;
+    // (a frame of zeros decodes one symbol per window at worst: a bound on the windows that no stream reaches)
+    uint32_t guard = (n0 + 2u * n1 + 1u) * 80u + 1024u;
+
+    auto refill = [&]() {
+        if (atMarker) {  // zeros from here on
+#pragma unroll
+            for (int j = 0; j < 4; j++) ring8[(wp + 4u * (uint32_t)lane + (uint32_t)j) & (kRingBytes - 1)] = 0;
+            wp += kRefillBytes;
+            return;
+        }
+        const uint32_t at = rp + 4u * (uint32_t)lane;
+        uint32_t w;
+        __builtin_memcpy(&w, p + at, 4);  // (the byte buffer is padded: the load is in bounds wherever the frame ends)
+        const uint32_t nextW = (uint32_t)__builtin_amdgcn_update_dpp((int)0, (int)w, 0x130, 0xf, 0xf, false);  // wave_shl:1 = lane + 1's word
+        const uint32_t prevW = (uint32_t)__builtin_amdgcn_update_dpp((int)0, (int)w, 0x138, 0xf, 0xf, false);  // wave_shr:1 = lane - 1's word
+        const uint32_t peek = lane == 63 ? (uint32_t)p[rp + kRefillBytes] : (nextW & 255u);
+        const uint32_t before = lane == 0 ? prevByte : prevW >> 24;
+        uint32_t keep = 0, cutHere = 4;  // cutHere: first byte of this lane at which the chunk ends (marker or end of data)
+#pragma unroll
+        for (int j = 3; j >= 0; j--) {
+            const uint32_t b = (w >> (8 * j)) & 255u;
+            const uint32_t nx = j < 3 ? (w >> (8 * j + 8)) & 255u : peek;
+            const uint32_t pv = j > 0 ? (w >> (8 * j - 8)) & 255u : before;
+            const bool ends = at + (uint32_t)j >= limit || (b == 0xFFu && (at + (uint32_t)j + 1u >= limit || nx != 0u));
+            if (ends) cutHere = (uint32_t)j;
+            if (!(b == 0u && pv == 0xFFu)) keep |= 1u << j;
+        }
+        const unsigned long long cutMask = __ballot(cutHere < 4u);
+        uint32_t cut = kRefillBytes;
+        if (cutMask) {
+            const int L = __ffsll((long long)cutMask) - 1;
+            cut = 4u * (uint32_t)L + (uint32_t)__builtin_amdgcn_readlane((int)cutHere, L);
+        }
+        // bytes of this lane that go to the ring: kept and before the cut
+        const uint32_t mine = cut > 4u * (uint32_t)lane ? min(cut - 4u * (uint32_t)lane, 4u) : 0u;
+        keep &= (1u << mine) - 1u;
+        const uint32_t cnt = (uint32_t)__popc(keep);
+        const unsigned long long b0 = __ballot(cnt & 1u), b1 = __ballot(cnt & 2u), b2 = __ballot(cnt & 4u);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        uint32_t at8 = wp + (uint32_t)__popcll(b0 & below) + 2u * (uint32_t)__popcll(b1 & below) + 4u * (uint32_t)__popcll(b2 & below);
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (keep & (1u << j)) ring8[(at8++) & (kRingBytes - 1)] = (uint8_t)(w >> (8 * j));
+        wp += (uint32_t)__popcll(b0) + 2u * (uint32_t)__popcll(b1) + 4u * (uint32_t)__popcll(b2);
+        rp += cut;
+        if (cut < (uint32_t)kRefillBytes) atMarker = true;
+        else prevByte = (uint32_t)__builtin_amdgcn_readlane((int)(w >> 24), 63);
+    };
+
+    while (!done && !bad) {
+        if (restartNow) {
+            // the rest of the interval is padding; the marker follows (after fill bytes)
+            while (!atMarker) refill();
+            while (rp + 1u < limit && p[rp] == 0xFF && p[rp + 1] == 0xFF) rp++;
+            if (rp + 1u < limit && p[rp] == 0xFF && p[rp + 1] == (uint32_t)(0xD0 + nextRst)) {
+                rp += 2;
+                atMarker = false;
+                nextRst = (nextRst + 1) & 7;
+                pred0 = pred1 = pred2 = 0;
+                toRestart = d.restart;
+                P = 0;
+                wp = 0;
+                prevByte = 0;
+            } else {
+                bad = true;
+                break;
+            }
+            restartNow = false;
+        }
+        while (wp - (P >> 3) < (uint32_t)kRingNeed) {
+            wave_lds_order();
+            refill();
+        }
+        wave_lds_order();
+        // ---- every lane: the symbol that would start at its offset, under each table ----
+        const uint32_t o = P + (uint32_t)lane;
+        const uint32_t hi = __builtin_bswap32(s_ring[(o >> 5) & (kRingBytes / 4 - 1)]), lo = __builtin_bswap32(s_ring[((o >> 5) + 1u) & (kRingBytes / 4 - 1)]);
+        const uint32_t w = (uint32_t)(((((uint64_t)hi << 32) | lo) << (o & 31u)) >> 32);
+        const uint32_t pkD0 = huff_symbol(s_tab, lim[0], w, true), pkD1 = huff_symbol(s_tab + kHuffTableBytes, lim[1], w, true);
+        const uint32_t pkA0 = huff_symbol(s_tab + 2 * kHuffTableBytes, lim[2], w, false), pkA1 = huff_symbol(s_tab + 3 * kHuffTableBytes, lim[3], w, false);
+        // ---- the symbols that are there: the chain from offset 0 (scalar: every value here is the wave's) ----
+        int offv = -1, valv = 0;
+        uint32_t pos = 0;
+        while (pos < 64u) {
+            if (k == 0) {
+                // a block begins: its DC symbol
+                const int td = c == 0 ? d.td[0] : c == 1 ? d.td[1] : d.td[2];
+                const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)(td ? pkD1 : pkD0), (int)pos);
+                if (r & (1u << 11)) { bad = true; break; }
+                int pr = c == 0 ? pred0 : c == 1 ? pred1 : pred2;
+                pr += (int)r >> 16;
+                if (c == 0) pred0 = pr; else if (c == 1) pred1 = pr; else pred2 = pr;
+                const uint32_t bwc = c == 0 ? bw0 : (uint32_t)d.mcux;
+                const uint32_t row = c == 0 ? my * d.vmax + (uint32_t)by : my, col = c == 0 ? mx * d.hmax + (uint32_t)bx : mx;
+                block = ((c == 0 ? 0u : c == 1 ? n0 : n0 + n1) + row * bwc + col) * 64u;
+                offv = lane == (int)pos ? (int)block : offv;
+                valv = lane == (int)pos ? pr : valv;
+                k = 1;
+                pos += r & 63u;
+                if (pos >= 64u) break;
+            }
+            // the block's AC symbols: the plain ones (a run and a value) in a tight loop
+            const int ta = c == 0 ? d.ta[0] : c == 1 ? d.ta[1] : d.ta[2];
+            const uint32_t pkA = ta ? pkA1 : pkA0;
+            while (k < 64 && pos < 64u) {
+                // plain coefficients (a run and a value): one exit test per symbol
+                uint32_t r;
+                int kn;
+                bool plain;
+                for (;;) {
+                    r = (uint32_t)__builtin_amdgcn_readlane((int)pkA, (int)pos);
+                    kn = k + (int)((r >> 6) & 15u);
+                    plain = (r & (3u << 10)) == 0u && kn <= 63;
+                    if (!plain) break;
+                    offv = lane == (int)pos ? (int)(block + (uint32_t)kn) : offv;
+                    valv = lane == (int)pos ? (int)r >> 16 : valv;
+                    k = kn + 1;
+                    pos += r & 63u;
+                    if (!(k < 64 && pos < 64u)) break;
+                }
+                if (plain) break;  // the block or the window is used up
+                // end of block, a run of sixteen zeros, a code that does not exist or a run past the block's end
+                if ((r & (1u << 11)) || !(r & (1u << 10))) { bad = true; break; }
+                k = ((r >> 6) & 15u) == 15u ? k + 16 : 64;
+                pos += r & 63u;
+            }
+            if (bad) break;
+            if (k >= 64) {
+                k = 0;
+                const int hc = c == 0 ? d.hmax : 1, vc = c == 0 ? d.vmax : 1;
+                if (++bx == hc) {
+                    bx = 0;
+                    if (++by == vc) {
+                        by = 0;
+                        if (++c == d.nc) {
+                            c = 0;
+                            if (++mx == d.mcux) { mx = 0; my++; }
+                            if (my == d.mcuy) { done = true; break; }
+                            if (d.restart && --toRestart == 0) { restartNow = true; break; }
+                        }
+                    }
+                }
+            }
+        }
+        if (offv >= 0) fcoef[offv] = (int16_t)valv;
+        P += pos;
+        if (--guard == 0u) bad = true;
+    }
+    if (bad && lane == 0) status[f] = 1;
 }
 
 // ---- dequantisation + inverse DCT -----------------------------------------------------------------------------------
@@ -731,13 +960,30 @@ int jpeg_decode_batch(JpegState* s, hipStream_t st, const uint8_t* const* jpegs,
             }
             framesOfSet[(size_t)it->second].push_back(i);
         }
+        // frames with at most two DC and two AC tables take a wavefront each (k_jpeg_huff_wave); the others share
+        // wavefronts, kHuffLanes frames of one table set to each (k_jpeg_huff)
         groups.clear();
-        for (size_t set = 0; set < framesOfSet.size(); set++)
-            for (size_t k = 0; k < framesOfSet[set].size(); k += kHuffLanes) {
-                groups.push_back((int32_t)set);
-                for (size_t j = 0; j < (size_t)kHuffLanes; j++) groups.push_back(k + j < framesOfSet[set].size() ? framesOfSet[set][k + j] : -1);
+        std::vector<int32_t> waveList;
+        for (size_t set = 0; set < framesOfSet.size(); set++) {
+            std::vector<int> shared;
+            for (int i : framesOfSet[set]) {
+                if (!pf[(size_t)i].dc[2].set && !pf[(size_t)i].ac[2].set) {
+                    waveList.push_back(i);
+                    waveList.push_back((int32_t)set);
+                } else {
+                    shared.push_back(i);
+                }
             }
+            for (size_t k = 0; k < shared.size(); k += kHuffLanes) {
+                groups.push_back((int32_t)set);
+                for (size_t j = 0; j < (size_t)kHuffLanes; j++) groups.push_back(k + j < shared.size() ? shared[k + j] : -1);
+            }
+        }
         const int nGroups = (int)(groups.size() / (1 + kHuffLanes));
+        const int nWave = (int)(waveList.size() / 2);
+        const size_t waveOff = groups.size();
+        groups.insert(groups.end(), waveList.begin(), waveList.end());
+        if (groups.empty()) groups.push_back(0);
         descs.resize((size_t)nb);
         quant.resize((size_t)nb * 256);
         for (int i = 0; i < nb; i++) {
@@ -781,8 +1027,12 @@ int jpeg_decode_batch(JpegState* s, hipStream_t st, const uint8_t* const* jpegs,
         // ---- the three kernels ----
         uint8_t* const dst = outOnDevice ? out + (size_t)b0 * H * W * 3 : s->d_out;
         s->coefDirty = true;  // (until the inverse DCT has put the zeros back)
-        hipLaunchKernelGGL(k_jpeg_huff, dim3((unsigned)nGroups), dim3(64), 0, st, s->d_bytes, s->d_desc, s->d_groups, s->d_tables,
-                           s->d_coef, frameBlocks, s->d_status);
+        if (nGroups)
+            hipLaunchKernelGGL(k_jpeg_huff, dim3((unsigned)nGroups), dim3(64), 0, st, s->d_bytes, s->d_desc, s->d_groups, s->d_tables,
+                               s->d_coef, frameBlocks, s->d_status);
+        if (nWave)
+            hipLaunchKernelGGL(k_jpeg_huff_wave, dim3((unsigned)nWave), dim3(64), 0, st, s->d_bytes, s->d_desc, s->d_groups + waveOff,
+                               s->d_tables, s->d_coef, frameBlocks, s->d_status);
         hipLaunchKernelGGL(k_jpeg_idct, dim3((frameBlocks + kIdctBlocksPerWg - 1) / kIdctBlocksPerWg, (unsigned)nb), dim3(256), 0, st,
                            s->d_coef, s->d_desc, s->d_quant, s->d_planes, frameBlocks, (const int32_t*)nullptr);
         const unsigned colorBlocks = (unsigned)(((size_t)H * ((W + 3) / 4) + 255) / 256);

@@ -60,6 +60,32 @@ def strip_dht(data):
     return bytes(out + data[i:])
 
 
+def third_tables(data):
+    """The same image with the Cr component coded with Huffman tables 2 (copies of tables 1): a frame with three DC and
+    three AC tables, which the decoder's wave-per-frame kernel leaves to the shared-wave one."""
+    out = bytearray(data[:2])
+    i = 2
+    extra = bytearray()
+    while data[i + 1] != 0xDA:
+        L = (data[i + 2] << 8) | data[i + 3]
+        seg = data[i:i + 2 + L]
+        out += seg
+        if data[i + 1] == 0xC4:
+            k = 4
+            while k < len(seg):
+                n = sum(seg[k + 1:k + 17])
+                if seg[k] & 15 == 1:
+                    extra += bytes([0xFF, 0xC4, 0, 0]) + bytes([(seg[k] & 0xF0) | 2]) + seg[k + 1:k + 17 + n]
+                    extra[-(n + 17 + 2):-(n + 17)] = (n + 19).to_bytes(2, "big")
+                k += 17 + n
+        i += 2 + L
+    L = (data[i + 2] << 8) | data[i + 3]
+    sos = bytearray(data[i:i + 2 + L])
+    assert sos[4] == 3
+    sos[5 + 2 * 2 + 1] = 0x22
+    return bytes(out + extra + sos + data[i + 2 + L:])
+
+
 VARIANTS = [
     dict(quality=90, subsampling=0), dict(quality=75, subsampling=1), dict(quality=60, subsampling=2),
     dict(quality=95, subsampling=2, optimize=True), dict(quality=30, subsampling=1, restart_marker_blocks=3),
@@ -92,6 +118,15 @@ def test_mjpeg_frames_without_huffman_tables():
     bare = strip_dht(data)
     assert len(bare) < len(data) and b"\xff\xc4" not in bare[:600]
     assert np.array_equal(orc.jpeg_decode(bare), _pil_bgr(data))
+
+
+def test_frames_with_three_huffman_tables():
+    img = _scene(64, 96, 11)
+    for kw in (dict(quality=80, subsampling=0), dict(quality=70, subsampling=2, optimize=True)):
+        data = _encode(img, **kw)
+        three = third_tables(data)
+        assert three != data and np.array_equal(_pil_bgr(three), _pil_bgr(data))
+        assert np.array_equal(orc.jpeg_decode(three), _pil_bgr(data))
 
 
 def test_what_the_decoder_does_not_take():
@@ -130,7 +165,9 @@ def test_gpu_decodes_every_supported_kind_like_the_oracle(hw):
     datas = [_encode(img, **kw) for kw in VARIANTS]
     datas.append(_encode(img[..., 0], quality=80))
     datas.append(strip_dht(_encode(img, quality=80, subsampling=1)))
-    datas += [_encode(_scene(hw[0], hw[1], s), quality=70 + s, subsampling=s % 3) for s in range(70)]  # more than one group of 64
+    datas += [_encode(_scene(hw[0], hw[1], s), quality=70 + s, subsampling=s % 3) for s in range(70)]
+    # frames with three Huffman tables per class (the shared-wave kernel), more than one wave of them
+    datas += [third_tables(_encode(_scene(hw[0], hw[1], 100 + s), quality=60 + s, subsampling=s % 3)) for s in range(9)]
     ctx = _hip.Context(max(hw[0], 32), max(hw[1], 32), 8)
     got = ctx.decode_jpeg(datas)
     for i, d in enumerate(datas):
