@@ -84,6 +84,8 @@ struct camsync_ctx {
     size_t calCapPts = 0, calCapV = 0;  // what the calibration buffers were sized for
     int calCapNI = 0;
     double* h_pin = nullptr;       // pinned host doubles for the small read-backs of the LM loop
+    double* h_report = nullptr;    // coherent host memory the LM kernel reports to on one GPU: 7 doubles, sequence number at [8]
+    unsigned long long calSeq = 0;
     // pinned host copies of a chunk's detection results (allocated on first use, kept for the context's life)
     int32_t *h_ids = nullptr, *h_counts = nullptr, *h_rejCounts = nullptr;
     float *h_corners = nullptr, *h_rej = nullptr;
@@ -715,6 +717,8 @@ int camsync_create(camsync_ctx** out, int device, int max_h, int max_w, int max_
     HIPCHK(c, hipMemcpy(c->d_expTab, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
     for (int i = 0; i <= CAMSYNC_N_STAGES; i++) HIPCHK(c, hipEventCreate(&c->ev[i]));
     HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_pin), sizeof(double) * 256, hipHostMallocDefault));
+    HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_report), sizeof(double) * 16, hipHostMallocMapped | hipHostMallocCoherent));
+    memset(c->h_report, 0, sizeof(double) * 16);
     return CAMSYNC_OK;
 }
 
@@ -746,6 +750,7 @@ void camsync_destroy(camsync_ctx* c) {
         if (p) (void)hipFree(p);
     jpeg_destroy(c->jpeg);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
+    if (c->h_report) (void)hipHostFree(c->h_report);
     void* hostPtrs[] = {c->h_ids, c->h_corners, c->h_counts, c->h_rejCounts, c->h_rej};
     for (void* p : hostPtrs)
         if (p) (void)hipHostFree(p);
@@ -1888,10 +1893,35 @@ static int calibrate_impl(camsync_ctx* c, const float* obj, const float* img, in
     // One kernel and one all-reduce per trial step (k_calib.hip): the kernel that evaluates a trial also forms the
     // trial parameters' record, damped as the next iteration will want it if the trial is accepted.
     auto lambda_of = [](int lg10) { return exp(lg10 * log(10.)); };
+    // On one GPU (no all-reduce) the kernel's last workgroup reports what the loop decides from straight into host
+    // memory and the host polls a sequence number: no copy to enqueue, no stream to wait for.
+    double* d_report = nullptr;
+    if (!ar) HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void**>(&d_report), c->h_report, 0));
     auto evaluate = [&](int mode, int lg10) -> int {
-        launch_calib_lm(s, mode, lambda_of(lg10), work, c->stream);
+        launch_calib_lm(s, mode, lambda_of(lg10), work, c->stream, d_report, ++c->calSeq);
         HIPCHK(c, hipGetLastError());
         return allreduce(work + kWAcc, L + 2);
+    };
+    // hp <- [err(trial), change sums of the extrinsics, | change sums of the intrinsics, flag, old err] of the last evaluate
+    auto read_back = [&](double* out7) -> int {
+        if (d_report) {
+            volatile unsigned long long* const seq = reinterpret_cast<volatile unsigned long long*>(c->h_report + 8);
+            for (unsigned long spins = 0; *seq != c->calSeq; spins++) {
+                if ((spins & 0xFFFF) == 0xFFFF) {  // (a kernel that failed never reports: ask the stream now and then)
+                    const hipError_t q = hipStreamQuery(c->stream);
+                    if (q != hipErrorNotReady && *seq != c->calSeq)
+                        return fail(c, CAMSYNC_E_HIP, "the calibration kernel ended without its report: %s", hipGetErrorString(q));
+                }
+            }
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);
+            for (int i = 0; i < 7; i++) out7[i] = c->h_report[i];
+            return CAMSYNC_OK;
+        }
+        HIPCHK(c, hipMemcpyAsync(hp, work + kWAcc + L - 1, sizeof(double) * (kWRec + 4 - (L - 1)), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (int i = 0; i < 3; i++) out7[i] = hp[i];
+        for (int i = 0; i < 4; i++) out7[3 + i] = hp[kWRec - (L - 1) + i];
+        return CAMSYNC_OK;
     };
     int lambdaLg10 = -3, it = 0;
     double prevErr = 0, errNorm = 0;
@@ -1902,13 +1932,13 @@ static int calibrate_impl(camsync_ctx* c, const float* obj, const float* img, in
         const int nextLg10 = std::max(lambdaLg10 - 1, -16);
         rc = evaluate(1, nextLg10);
         if (rc) return rc;
-        // one read-back: [err(trial), change sums of the extrinsics ... change sums of the intrinsics, flag, old err]
-        HIPCHK(c, hipMemcpyAsync(hp, work + kWAcc + L - 1, sizeof(double) * (kWRec + 4 - (L - 1)), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        const double* const rep = hp + (kWRec - (L - 1));
+        double r7[7];
+        rc = read_back(r7);
+        if (rc) return rc;
+        const double* const rep = r7 + 3;
         if (rep[2] != 0.0) return fail(c, CAMSYNC_E_NUMERIC, "intrinsic block is singular");
         if (it == 0) prevErr = rep[3];
-        errNorm = hp[0];
+        errNorm = r7[0];
         if (errNorm > prevErr && ++lambdaLg10 <= 16) {
             // rejected: the same parameters with more damping
             rc = evaluate(0, lambdaLg10);
@@ -1917,7 +1947,7 @@ static int calibrate_impl(camsync_ctx* c, const float* obj, const float* img, in
         }
         lambdaLg10 = std::max(lambdaLg10 - 1, -16);
         // relative parameter change ||p - p_prev|| / ||p_prev|| (extrinsics of all ranks, intrinsics once)
-        const double change = sqrt(hp[1] + rep[0]) / sqrt(hp[2] + rep[1]);
+        const double change = sqrt(r7[1] + rep[0]) / sqrt(r7[2] + rep[1]);
         calib_swap(s);
         if (++it >= max_iter || change < 2.220446049250313e-16) break;
         prevErr = errNorm;

@@ -347,7 +347,9 @@ uint32_t rotate_marker_code(uint32_t code, int n, int r);
 size_t seed_table_entries(int H, int W);
 int calib_lm_grid(int V);
 void launch_fill_i32(int32_t* dst, int n, int32_t value, hipStream_t st);
-void launch_calib_lm(const CalibState& s, int mode, double lambda, double* work, hipStream_t st);
+// report / seq: see k_calib_lm (host-visible copy of what the LM loop decides from; null = none)
+void launch_calib_lm(const CalibState& s, int mode, double lambda, double* work, hipStream_t st, double* report = nullptr,
+                     unsigned long long seq = 0);
 void launch_calib_focal_rows(const CalibState& s, double cx, double cy, double* rows, double* acc6, hipStream_t st);
 
 }  // namespace camsync

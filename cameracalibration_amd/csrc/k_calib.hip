@@ -63,7 +63,8 @@ constexpr int kLmGroup = 32;      // records summed per level of the final reduc
 // [sum (intr_trial - intr)^2, sum intr^2, solver flag (1: singular), err of the record that was solved] and the step
 // in work[kWDelta..].
 template <int NI>
-__global__ __launch_bounds__(64 * kLmWaves) void k_calib_lm(CalibState s, int mode, double lambda, double* __restrict__ work) {
+__global__ __launch_bounds__(64 * kLmWaves) void k_calib_lm(CalibState s, int mode, double lambda, double* __restrict__ work,
+                                                            double* __restrict__ report, unsigned long long seq) {
     constexpr int L = NI * NI + NI + 1;
     constexpr int NC = NI + 7;           // columns of [Je | Ji | e]
     constexpr int LD = (NC | 1) + 1;     // row stride: even (16-byte rows), not a multiple of 16 doubles
@@ -344,7 +345,9 @@ __global__ __launch_bounds__(64 * kLmWaves) void k_calib_lm(CalibState s, int mo
 #pragma unroll
         for (int i = 1; i < kLmGroup; i++) t += v[i];
         work[tid] = t;
+        if (report && tid >= L - 1) comb[0][tid - (L - 1)] = t;  // [err, change sums of the extrinsics]: for the host, below
     }
+    if (report) __syncthreads();
     if (tid == 0) {
         double di = 0, pi = 0;
         for (int i = 0; i < 12; i++) {
@@ -359,6 +362,15 @@ __global__ __launch_bounds__(64 * kLmWaves) void k_calib_lm(CalibState s, int mo
         work[kWRec + 3] = step[NI + 1];
         for (int i = 0; i < 12; i++) work[kWDelta + i] = i < NI ? step[i] : 0.0;
         *s.ticket = 0u;
+        if (report) {
+            // One GPU: what the host decides the next step from goes straight into its (page-locked, coherent) memory,
+            // and a sequence number after it -- the host polls that instead of enqueueing a copy and waiting for the
+            // stream, which cost several times the kernel's 33 us.
+            report[0] = comb[0][0]; report[1] = comb[0][1]; report[2] = comb[0][2];
+            report[3] = di; report[4] = pi; report[5] = step[NI]; report[6] = step[NI + 1];
+            __threadfence_system();
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(report + 8), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -436,10 +448,10 @@ void launch_fill_i32(int32_t* dst, int n, int32_t value, hipStream_t st) {
 
 int calib_lm_grid(int V) { return min(max((V + kLmWaves - 1) / kLmWaves, 1), kLmGroup * kLmGroup); }
 
-void launch_calib_lm(const CalibState& s, int mode, double lambda, double* work, hipStream_t st) {
+void launch_calib_lm(const CalibState& s, int mode, double lambda, double* work, hipStream_t st, double* report, unsigned long long seq) {
     const int grid = calib_lm_grid(s.V);
-    if (s.NI == 9) hipLaunchKernelGGL(k_calib_lm<9>, dim3(grid), dim3(64 * kLmWaves), 0, st, s, mode, lambda, work);
-    else hipLaunchKernelGGL(k_calib_lm<12>, dim3(grid), dim3(64 * kLmWaves), 0, st, s, mode, lambda, work);
+    if (s.NI == 9) hipLaunchKernelGGL(k_calib_lm<9>, dim3(grid), dim3(64 * kLmWaves), 0, st, s, mode, lambda, work, report, seq);
+    else hipLaunchKernelGGL(k_calib_lm<12>, dim3(grid), dim3(64 * kLmWaves), 0, st, s, mode, lambda, work, report, seq);
 }
 
 void launch_calib_focal_rows(const CalibState& s, double cx, double cy, double* rows, double* acc6, hipStream_t st) {
