@@ -331,21 +331,21 @@ def main():
         from cameracalibration_amd.calibrate_dist import calibrate_distributed
         obj, img, _, _ = synth.calib_views(V=args.calib_views, seed=42, rational=True)
         if world == 1:
-            ctx.calibrate(obj[:64], img[:64], (1920, 1080), rational=True, max_iter=2)  # warm
-            t1 = time.perf_counter()
-            rms, _, _, _, _, iters = ctx.calibrate(obj, img, (1920, 1080), rational=True, max_iter=30)
-            t2 = time.perf_counter()
+            ctx.calibrate(obj, img, (1920, 1080), rational=True, max_iter=1)  # warm: the buffers of this problem size
             # the LM loop alone: the same problem limited to one iteration, subtracted
             t3 = time.perf_counter()
             ctx.calibrate(obj, img, (1920, 1080), rational=True, max_iter=1)
             t4 = time.perf_counter()
+            t1 = time.perf_counter()
+            rms, _, _, _, _, iters = ctx.calibrate(obj, img, (1920, 1080), rational=True, max_iter=30)
+            t2 = time.perf_counter()
             calib_inputs = (obj, img)
             calib = {"views": args.calib_views, "iters": iters, "iters_per_s": iters / (t2 - t1), "rms_px": rms,
                      "includes": "init (homographies + per-view PnP) + LM",
                      "lm_only_iters_per_s": (iters - 1) / max((t2 - t1) - (t4 - t3), 1e-9) if iters > 1 else None}
         else:
             stats = {}
-            calibrate_distributed(obj[:64 * world], img[:64 * world], (1920, 1080), rational=True, max_iter=2, device_index=local_rank)
+            calibrate_distributed(obj, img, (1920, 1080), rational=True, max_iter=1, device_index=local_rank)  # warm: buffers, communicator
             barrier()
             t1 = time.perf_counter()
             rms, _, _, _, _, span, iters = calibrate_distributed(obj, img, (1920, 1080), rational=True, max_iter=30,
