@@ -139,6 +139,19 @@ constexpr int kTraceWaves = 256 * 16;  // persistent single-wave workgroups of t
 constexpr int kCkStride = 256;         // points per copy task and chain chunk
 constexpr int kMaxBorder = 16380;       // longest border kept (maxMarkerPerimeterRate x the larger frame side must not exceed it)
 
+// Compute units of the current device (256 on MI355X), asked once per device: grids that are sized to what the chip
+// holds at once follow it.
+inline int device_cus() {
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (!cus[dev]) {
+        int n = 0;
+        cus[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    }
+    return cus[dev];
+}
+
 // Debugging aid (environment variable CAMSYNC_DEBUG_STAGES): wait for the stream after every kernel of the detection
 // sequence and report it on stderr, so that a failing kernel is named.  Off: one getenv at the first call.
 inline bool debug_stages() {

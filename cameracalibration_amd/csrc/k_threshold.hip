@@ -567,7 +567,7 @@ void launch_gray_thresh(const DetCfg& c, const DetBuffers& b, int B, int C, hipS
         // round that is mostly empty costs as much as a full one.  Choose the number of bands per strip that
         // minimises rounds x band length; every band re-reads 2 rmax + 2 rows above it to warm its running sums
         // up (about 12 rows' worth of time), and bands are whole plane blocks.
-        const long slots = 256L * 12;
+        const long slots = (long)device_cus() * 12;
         const int maxBands = max(1, (c.H + 63) / 64);
         int bands = 1, bandH = (c.H + 31) & ~31;
         long best = -1;
