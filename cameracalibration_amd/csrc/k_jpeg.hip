@@ -28,6 +28,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace camsync {
@@ -1015,9 +1016,28 @@ int jpeg_decode_batch(JpegState* s, hipStream_t st, const uint8_t* const* jpegs,
             if ((e = hipMemsetAsync(s->d_coef, 0, s->coefCap * sizeof(int16_t), st)) != hipSuccess) return hipfail("hipMemsetAsync", e);
             s->coefDirty = false;
         }
-        memset(s->h_bytes, 0, totalBytes);
-        for (int i = 0; i < nb; i++)
-            memcpy(s->h_bytes + pf[(size_t)i].d.dataOff, jpegs[b0 + i] + pf[(size_t)i].scanOff, pf[(size_t)i].d.dataLen);
+        // the frames' entropy-coded bytes, packed (16-byte aligned each, zeros in between and after the last): with
+        // hundreds of megabytes to move this is a good part of the call, so several threads share it
+        {
+            auto pack = [&](int i0, int i1) {
+                for (int i = i0; i < i1; i++) {
+                    const JpegDesc& d = pf[(size_t)i].d;
+                    uint8_t* dst = s->h_bytes + d.dataOff;
+                    memcpy(dst, jpegs[b0 + i] + pf[(size_t)i].scanOff, d.dataLen);
+                    const size_t end = i + 1 < nb ? pf[(size_t)i + 1].d.dataOff : totalBytes;
+                    memset(dst + d.dataLen, 0, end - d.dataOff - d.dataLen);
+                }
+            };
+            const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+            const int nt = totalBytes < ((size_t)32 << 20) ? 1 : (int)std::min<unsigned>(std::min<unsigned>(hw, 8u), (unsigned)nb);
+            if (nt <= 1) {
+                pack(0, nb);
+            } else {
+                std::vector<std::thread> th;
+                for (int t = 0; t < nt; t++) th.emplace_back(pack, (int)((long long)nb * t / nt), (int)((long long)nb * (t + 1) / nt));
+                for (auto& x : th) x.join();
+            }
+        }
         if ((e = hipMemcpyAsync(s->d_bytes, s->h_bytes, totalBytes, hipMemcpyHostToDevice, st)) != hipSuccess) return hipfail("hipMemcpyAsync", e);
         if ((e = hipMemcpyAsync(s->d_desc, descs.data(), sizeof(JpegDesc) * nb, hipMemcpyHostToDevice, st)) != hipSuccess) return hipfail("hipMemcpyAsync", e);
         if ((e = hipMemcpyAsync(s->d_quant, quant.data(), quant.size() * 2, hipMemcpyHostToDevice, st)) != hipSuccess) return hipfail("hipMemcpyAsync", e);
