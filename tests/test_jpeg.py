@@ -198,6 +198,21 @@ def test_gpu_refuses_what_the_decoder_does_not_take():
     except _hip.CamsyncError as e2:
         assert e2.code == _hip.E_ARG
     assert np.array_equal(ctx.decode_jpeg([good])[0], orc.jpeg_decode(good))
+    # garbled entropy-coded bytes (no new markers), through both Huffman kernels: codes that do not exist, runs past a
+    # block's end, a stream that ends early or late
+    rng = np.random.default_rng(11)
+    sos = good.index(b"\xff\xda")
+    for trial in range(8):
+        b = bytearray(good if trial % 2 == 0 else third_tables(good))
+        first = (sos if trial % 2 == 0 else bytes(b).index(b"\xff\xda")) + 14
+        for at in rng.integers(first, len(b) - 2, 12):
+            b[at] = int(rng.integers(0, 255))
+        try:
+            out = ctx.decode_jpeg([good, bytes(b)])
+            assert np.array_equal(out[0], orc.jpeg_decode(good))
+        except _hip.CamsyncError as e3:
+            assert e3.code == _hip.E_ARG
+    assert np.array_equal(ctx.decode_jpeg([good])[0], orc.jpeg_decode(good))
 
 
 @pytest.mark.gpu
