@@ -79,7 +79,9 @@ const char* camsync_last_error(const camsync_ctx* ctx);
  * buffers from camsync_host_alloc are page-locked: a capture or decode library that writes its frames there (V4L2
  * user pointers, a decoder's output surface) spares the staging copy the driver makes of pageable memory, and the
  * host-to-device copies of the *_batch entry points run at the link's rate (measured: DESIGN.md section 6).  Any
- * host pointer is accepted by those entry points; these two calls only provide the fast kind.  The memory is not
+ * host pointer is accepted by those entry points; these two calls only provide the fast kind (frames in ordinary
+ * memory are staged by the detection entry points themselves: up to eight short-lived threads of the calling process
+ * copy them piecewise into a page-locked buffer of 64 MB that the context keeps).  The memory is not
  * tied to a context (it may be shared by the contexts of several GPUs). */
 int camsync_host_alloc(void** out, size_t bytes);
 int camsync_host_free(void* p);
