@@ -305,6 +305,38 @@ def test_page_locked_frame_buffers_give_the_same_result():
     pinned.close()
 
 
+def test_host_frames_larger_than_the_upload_buffer_arrive_intact():
+    """Frames in ordinary host memory are staged through a 64 MB page-locked buffer by several threads (upload_host): a
+    batch of 75 MB goes round that buffer, one of 12 MB takes the small pieces, separate frames arrive as a batch does
+    -- all give what the same frames give from page-locked memory, which is sent as it is."""
+    K, _ = _data.calibration("Logitec_robot_1920-1080_10.npz")
+    base = [synth.v1_frame(40 + i, K, ss=2)[0].numpy() for i in range(3)]
+    rng = np.random.default_rng(5)
+    frames = np.stack([np.clip(base[i % 3].astype(np.int16) + rng.integers(-3, 4, base[0].shape), 0, 255).astype(np.uint8)
+                       for i in range(12)])
+    assert frames.nbytes > 64 << 20
+    ctx = _hip.Context(1080, 1920, 12)
+    pinned = _hip.PinnedFrames(frames.shape)
+    pinned.array[...] = frames
+    want = ctx.detect(pinned.array)
+    assert int(want[2].min()) >= 4
+    for got in (ctx.detect(frames), ctx.detect(frames)):
+        for a, b in zip(want, got):
+            assert np.array_equal(a, b)
+    two = ctx.detect(frames[5:7])
+    for a, b in zip(want, two):
+        assert np.array_equal(a[5:7], b)
+    anchors = [10, 11, 14, 15]
+    obj = _data.v1_anchor_points(anchors)
+    sep = ctx.detect_pnp_frames([frames[i] for i in range(12)], anchors, obj, K, np.zeros(5), 64)
+    assert np.array_equal(sep[0], want[0]) and np.array_equal(sep[1], want[1]) and np.array_equal(sep[2], want[2])
+    ref = ctx.detect_pnp(pinned.array, anchors, obj, K, np.zeros(5), 64)
+    assert ref[5].any()
+    for a, b in zip(ref, sep):
+        assert np.array_equal(a, b)
+    pinned.close()
+
+
 def test_fall_back_candidate_when_the_representative_is_no_marker():
     """A thin black ring close around a marker: the ring's outer quad is the largest of the group of near-duplicates
     (so it is the one selected) and is no marker; the detector then falls back to the marker's own quad.  The pipeline
