@@ -647,8 +647,9 @@ __device__ __forceinline__ void adopt_orphans(WaveAlloc& slotA, WaveAlloc& taskA
 // stage: 8: 5.10, 16: 4.34, 20: 4.31, 24: 4.33, 32: 4.43, 48: 4.56, 64: 4.79 -- the 5 % of the candidates that use the
 // whole budget cost a third of this pass's iterations at 48, and the segment followers take them over for less).
 // The two followers also notice when they meet (SHORT_MEET): a border of up to twice the budget is then known all
-// round -- its length and that no crack on it has a smaller key -- and is decided here; at 1080p every border below
-// the minimum perimeter (58 points) that way.  Border stage with it, bench / photo scene in ms, budget 16: 3.88 / 7.02,
+// round -- its length and that no crack on it has a smaller key -- and is decided here (a budget of 30 would decide
+// every border below 1080p's minimum perimeter of 58 points, but costs more than it saves).  Border stage with it,
+// bench / photo scene in ms, budget 16: 3.88 / 7.02,
 // 20: 3.90 / 6.99, 24: 3.94 / 7.19, 30: 4.06 / 7.37; without it at 24: 3.95 / 7.42.
 #ifndef SHORT_BUDGET
 #define SHORT_BUDGET 20
