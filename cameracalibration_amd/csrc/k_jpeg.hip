@@ -495,6 +495,297 @@ __global__ __launch_bounds__(64) void k_jpeg_huff_wave(const uint8_t* __restrict
     if (bad && lane == 0) status[f] = 1;
 }
 
+// ---- entropy decoding, many lanes per frame ---------------------------------------------------------------------------
+// A Huffman stream can be entered anywhere: a decoder that starts at an arbitrary bit with a guessed state (which block
+// of the MCU, which coefficient) reads nonsense for a while and then, with high probability, falls into step with the
+// real decoder -- from there on it produces what the real one does.  So the frame's stream (byte stuffing removed first,
+// k_jpeg_unstuff) is cut into subsequences of kParBits bits with a lane each.  A record per subsequence holds where and in
+// which state the decoder leaves it: (bit position of the first symbol beyond it, block of the MCU, coefficient) and the
+// number of blocks completed inside it.  k_jpeg_par<false> makes every lane decode its subsequence from the state its
+// predecessor's record names (at first a guess: the subsequence's first bit, start of an MCU) and write its own record;
+// lanes whose entry state has not changed since they last ran do nothing.  Lane 0 enters with the true state, so after
+// r rounds the first r records are true; because of the self-synchronisation nearly all are after three or four, and
+// a round in which no record changes proves that every record follows from its predecessor's, i.e. all are true.
+// k_jpeg_par<true> then decodes every subsequence once more from its true entry state, now knowing (prefix sum of the
+// block counts) which block it is in, and stores the coefficients; DC differences are stored as they are coded and
+// summed per component afterwards (k_jpeg_dc).  One 1080p frame: ~1900 lanes instead of one chain of 350 k symbols.
+// Frames with restart intervals, and frames whose records have not settled after kParMaxRounds rounds, take the
+// sequential kernels above.
+#ifndef PAR_BITS
+#define PAR_BITS 1024
+#endif
+constexpr uint32_t kParBits = PAR_BITS;  // a multiple of 32
+constexpr int kParMaxRounds = 64;
+constexpr unsigned long long kParStateMask = 0xFFFFFFFFFFFFull;  // position | block of the MCU << 32 | coefficient << 40
+
+// One workgroup per frame: the frame's entropy-coded bytes without the stuffed zeros (0xFF 0x00 -> 0xFF), up to the
+// first marker, zeros from there to the end of the frame's place in the buffer; its length in bits; its records set to
+// the guesses.  list[blockIdx.x] = frame.
+__global__ __launch_bounds__(256) void k_jpeg_unstuff(const uint8_t* __restrict__ bytes, const JpegDesc* __restrict__ desc,
+                                                      const int32_t* __restrict__ list, uint8_t* __restrict__ ubytes,
+                                                      uint32_t* __restrict__ ulenBits, const uint32_t* __restrict__ subBase,
+                                                      unsigned long long* __restrict__ exitRec, unsigned long long* __restrict__ lastEntry) {
+    __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t s_cut;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int f = list[blockIdx.x];
+    const JpegDesc d = desc[f];
+    const uint8_t* const src = bytes + d.dataOff;
+    uint8_t* const dst = ubytes + d.dataOff;
+    const uint32_t len = d.dataLen, place = (len + 15u) & ~15u;
+    uint32_t running = 0;  // bytes written so far (uniform)
+    for (uint32_t tile = 0; tile < len; tile += 4096u) {
+        if (tid == 0) s_cut = 0xFFFFFFFFu;
+        __syncthreads();
+        const uint32_t at = tile + 16u * (uint32_t)tid;
+        // (the byte buffer is padded beyond its last frame: these loads are in bounds wherever the frame ends)
+        const uint4 v = *reinterpret_cast<const uint4*>(src + at);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        const uint32_t before = at > 0 ? src[at - 1] : 0u, after = src[at + 16];
+        uint32_t keep = 0, myCut = 16;
+#pragma unroll
+        for (int j = 15; j >= 0; j--) {
+            const uint32_t b = (w[j >> 2] >> (8 * (j & 3))) & 255u;
+            const uint32_t nx = j < 15 ? (w[(j + 1) >> 2] >> (8 * ((j + 1) & 3))) & 255u : after;
+            const uint32_t pv = j > 0 ? (w[(j - 1) >> 2] >> (8 * ((j - 1) & 3))) & 255u : before;
+            if (at + (uint32_t)j >= len || (b == 0xFFu && nx != 0u)) myCut = (uint32_t)j;  // the data ends here
+            if (!(b == 0u && pv == 0xFFu)) keep |= 1u << j;
+        }
+        if (myCut < 16u) atomicMin(&s_cut, at + myCut);
+        __syncthreads();
+        const uint32_t cut = s_cut;
+        const uint32_t mine = cut > at ? min(cut - at, 16u) : 0u;
+        keep &= (1u << mine) - 1u;
+        const uint32_t cnt = (uint32_t)__popc(keep);
+        // exclusive prefix sum over the workgroup
+        uint32_t inc = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = (uint32_t)__shfl_up((int)inc, o);
+            if (lane >= o) inc += t;
+        }
+        if (lane == 63) s_wave[wave] = inc;
+        __syncthreads();
+        uint32_t base = running;
+        for (int k = 0; k < wave; k++) base += s_wave[k];
+        const uint32_t total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        uint32_t o = base + inc - cnt;
+#pragma unroll
+        for (int j = 0; j < 16; j++)
+            if (keep & (1u << j)) dst[o++] = (uint8_t)(w[j >> 2] >> (8 * (j & 3)));
+        running += total;
+        __syncthreads();
+        if (cut != 0xFFFFFFFFu) break;
+    }
+    for (uint32_t i = running + (uint32_t)tid; i < place; i += 256u) dst[i] = 0;
+    if (tid == 0) ulenBits[f] = running * 8u;
+    // records: the guess for subsequence i + 1 is (its first bit, start of an MCU)
+    const uint32_t nSub = (len * 8u + kParBits - 1u) / kParBits;  // (an upper bound of what the unstuffed stream needs)
+    for (uint32_t i = (uint32_t)tid; i < nSub; i += 256u) {
+        exitRec[subBase[f] + i] = (unsigned long long)((i + 1u) * kParBits);
+        lastEntry[subBase[f] + i] = ~0ull;
+    }
+}
+
+// wg*: per workgroup its frame and its first subsequence.  frameSet[f] = the frame's table set.  changed[0] is set when
+// a record changes, changed[1 + f] to `round` when one of frame f does.  skip[f] != 0: the frame takes the sequential
+// kernels.
+template <bool WRITE>
+__global__ __launch_bounds__(256) void k_jpeg_par(const uint8_t* __restrict__ ubytes, const JpegDesc* __restrict__ desc,
+                                                  const int32_t* __restrict__ wgFrame, const uint32_t* __restrict__ wgFirst,
+                                                  const uint8_t* __restrict__ tableSets, const int32_t* __restrict__ frameSet,
+                                                  const uint32_t* __restrict__ ulenBits, const uint32_t* __restrict__ subBase,
+                                                  unsigned long long* __restrict__ exitRec, unsigned long long* __restrict__ lastEntry,
+                                                  int32_t* __restrict__ changed, int round, const int32_t* __restrict__ skip,
+                                                  int16_t* __restrict__ coef, int16_t* __restrict__ dcs, uint32_t frameBlocks,
+                                                  int32_t* __restrict__ status) {
+    __shared__ __align__(16) uint8_t s_tab[kHuffSetTables * kHuffTableBytes];
+    __shared__ uint32_t s_red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int f = wgFrame[blockIdx.x];
+    if (skip[f]) return;
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(tableSets + (size_t)frameSet[f] * kHuffSetTables * kHuffTableBytes);
+        uint4* dst = reinterpret_cast<uint4*>(s_tab);
+        for (int i = tid; i < kHuffSetTables * kHuffTableBytes / 16; i += 256) dst[i] = src[i];
+    }
+    __syncthreads();
+    const JpegDesc d = desc[f];
+    const uint32_t first = wgFirst[blockIdx.x], i = first + (uint32_t)tid;
+    const uint32_t nSub = (ulenBits[f] + kParBits - 1u) / kParBits;
+    const bool valid = i < nSub;
+    unsigned long long* const rec = exitRec + subBase[f];
+    const unsigned long long entry = !valid ? 0ull : i == 0u ? 0ull : __hip_atomic_load(&rec[i - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kParStateMask;
+    if (!WRITE) {
+        if (!valid || entry == lastEntry[subBase[f] + i]) return;
+    }
+    const int hv = d.hmax * d.vmax, nbMcu = d.nc == 1 ? 1 : hv + 2;
+    const uint32_t totalBlocks = (uint32_t)d.mcux * d.mcuy * (uint32_t)nbMcu;
+    const uint32_t bw0 = (uint32_t)d.mcux * d.hmax, n0 = bw0 * ((uint32_t)d.mcuy * d.vmax), n1 = (uint32_t)d.mcux * d.mcuy;
+    // ---- WRITE: the number of the block this subsequence starts in = blocks completed in all the ones before it ----
+    uint32_t q = 0;
+    if (WRITE) {
+        uint32_t part = 0;
+        for (uint32_t t = (uint32_t)tid; t < first; t += 256u) part += (uint32_t)(rec[t] >> 48);
+        const uint32_t mineN = valid ? (uint32_t)(rec[i] >> 48) : 0u;
+        uint32_t inc = mineN;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = (uint32_t)__shfl_up((int)inc, o);
+            if (lane >= o) inc += t;
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) part += (uint32_t)__shfl_xor((int)part, o);
+        if (lane == 63) s_red[wave] = inc;
+        __syncthreads();
+        uint32_t before = 0;
+        for (int k = 0; k < wave; k++) before += s_red[k];
+        __syncthreads();
+        if (lane == 0) s_red[wave] = part;
+        __syncthreads();
+        q = s_red[0] + s_red[1] + s_red[2] + s_red[3] + before + inc - mineN;
+        if (!valid) return;
+    }
+    // ---- the decoder's state at the entry ----
+    const uint32_t p0 = (uint32_t)entry;
+    int j = (int)((entry >> 32) & 255u), k = (int)((entry >> 40) & 255u);
+    uint32_t nDone = 0;
+    bool bad = false;
+    if (WRITE && (q >= totalBlocks || (int)(q % (uint32_t)nbMcu) != j)) {
+        // beyond the image (padding of the stream's last bytes), or records that do not add up
+        if (q < totalBlocks) status[f] = 1;
+        return;
+    }
+    const uint32_t endBit = (i + 1u) * kParBits;
+    const uint32_t* const words = reinterpret_cast<const uint32_t*>(ubytes + d.dataOff);
+    uint32_t ptr = p0 >> 5;
+    uint64_t acc = (uint64_t)__builtin_bswap32(words[ptr]) << (32u + (p0 & 31u));
+    int nb = 32 - (int)(p0 & 31u);
+    ptr++;
+    int16_t* const fcoef = coef + (size_t)f * frameBlocks * 64;
+    int16_t* const fdc = dcs + (size_t)f * frameBlocks;
+    // where block number q is stored (WRITE), and its place among its component's blocks in coding order (+ the
+    // component's first block): the DC differences go to a compact array in that order (k_jpeg_dc)
+    uint32_t dcAt = 0;
+    auto storage = [&](uint32_t qq, int jj) -> uint32_t {
+        const uint32_t m = qq / (uint32_t)nbMcu, my = m / d.mcux, mx = m - my * d.mcux;
+        if (jj < hv) {
+            const uint32_t by = (uint32_t)jj / d.hmax, bx = (uint32_t)jj - by * d.hmax;
+            dcAt = m * (uint32_t)hv + (uint32_t)jj;
+            return ((my * d.vmax + by) * bw0 + mx * d.hmax + bx) * 64u;
+        }
+        dcAt = (jj == hv ? n0 : n0 + n1) + m;
+        return ((jj == hv ? n0 : n0 + n1) + m) * 64u;
+    };
+    uint32_t block = WRITE ? storage(q, j) : 0u;
+    while ((uint32_t)(ptr * 32u - (uint32_t)nb) < endBit) {
+        if (nb <= 32) {
+            acc |= (uint64_t)__builtin_bswap32(words[ptr]) << (32 - nb);
+            ptr++;
+            nb += 32;
+        }
+        const int c = j < hv ? 0 : j - hv + 1;
+        const int slot = k == 0 ? (c == 0 ? d.td[0] : c == 1 ? d.td[1] : d.td[2]) : 3 + (c == 0 ? d.ta[0] : c == 1 ? d.ta[1] : d.ta[2]);
+        const uint8_t* const T = s_tab + slot * kHuffTableBytes;
+        const uint32_t e = reinterpret_cast<const uint16_t*>(T)[(uint32_t)(acc >> 56)];
+        int l = (int)(e >> 8), sym = (int)(e & 255u);
+        if (!e) {
+            const uint32_t* lim = reinterpret_cast<const uint32_t*>(T + kOffLimit);
+            const uint32_t code16 = (uint32_t)(acc >> 48);
+            l = 9;
+#pragma unroll
+            for (int t = 9; t <= 15; t++) l += code16 >= lim[t] ? 1 : 0;
+            if (code16 >= lim[16]) bad = true;
+            const int32_t* valoff = reinterpret_cast<const int32_t*>(T + kOffValoff);
+            sym = T[kOffHuffval + (((int32_t)(code16 >> (16 - l)) + valoff[l]) & 255)];
+        }
+        acc <<= l;
+        nb -= l;
+        if (k == 0 && sym > 16) bad = true;
+        const int sz = k == 0 ? min(sym, 16) : (sym & 15);
+        int val = 0;
+        if (sz) {
+            const int r = (int)(acc >> (64 - sz));
+            acc <<= sz;
+            nb -= sz;
+            val = r < (1 << (sz - 1)) ? r - (1 << sz) + 1 : r;
+        }
+        if (k == 0) {
+            if (WRITE) fdc[dcAt] = (int16_t)val;  // the difference to the component's previous block (k_jpeg_dc)
+            k = 1;
+        } else {
+            const int run = sym >> 4;
+            if (sz) {
+                k += run;
+                if (k > 63) {
+                    bad = true;
+                    k = 64;
+                } else {
+                    if (WRITE) fcoef[block + (uint32_t)k] = (int16_t)val;
+                    k++;
+                }
+            } else {
+                k = run == 15 ? k + 16 : 64;
+            }
+        }
+        if (k >= 64) {
+            k = 0;
+            nDone++;
+            j = j + 1 == nbMcu ? 0 : j + 1;
+            if (WRITE) {
+                q++;
+                if (q >= totalBlocks) break;
+                block = storage(q, j);
+            }
+        }
+    }
+    if (WRITE) {
+        // (codes that do not exist and the like are the speculative decoders' daily bread; on the true path they mean a
+        // damaged frame, and so does a stream that ends before the image does)
+        if (bad || (i == nSub - 1u && q < totalBlocks)) status[f] = 1;
+    } else {
+        const unsigned long long out = (unsigned long long)(ptr * 32u - (uint32_t)nb) | ((unsigned long long)(uint32_t)j << 32) |
+                                       ((unsigned long long)(uint32_t)k << 40) | ((unsigned long long)min(nDone, 0xFFFFu) << 48);
+        lastEntry[subBase[f] + i] = entry;
+        if (out != rec[i]) {
+            __hip_atomic_store(&rec[i], out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            changed[0] = 1;
+            changed[1 + f] = round;
+        }
+    }
+}
+
+// DC coefficients from their differences: one workgroup per (component, frame) sums the component's differences in
+// the order they are coded (dcs: [frame][frameBlocks], a component's blocks together, component 0 first).  grid (3, frames in the list).
+__global__ __launch_bounds__(256) void k_jpeg_dc(int16_t* __restrict__ dcs, const JpegDesc* __restrict__ desc,
+                                                 const int32_t* __restrict__ list, const int32_t* __restrict__ skip, uint32_t frameBlocks) {
+    __shared__ int32_t s_wave[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int f = list[blockIdx.y], c = (int)blockIdx.x;
+    const JpegDesc d = desc[f];
+    if (skip[f] || c >= d.nc) return;
+    const uint32_t n0 = (uint32_t)d.mcux * d.hmax * ((uint32_t)d.mcuy * d.vmax), n1 = (uint32_t)d.mcux * d.mcuy;
+    const uint32_t nblk = c == 0 ? n0 : n1;
+    int16_t* const v = dcs + (size_t)f * frameBlocks + (c == 0 ? 0u : c == 1 ? n0 : n0 + n1);
+    const uint32_t per = (nblk + 255u) / 256u, lo = min((uint32_t)tid * per, nblk), hi = min(lo + per, nblk);
+    int32_t sum = 0;
+    for (uint32_t b = lo; b < hi; b++) sum += v[b];
+    int32_t inc = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int32_t t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    int32_t run = inc - sum;
+    for (int k = 0; k < wave; k++) run += s_wave[k];
+    for (uint32_t b = lo; b < hi; b++) {
+        run += v[b];
+        v[b] = (int16_t)run;
+    }
+}
+
 // ---- dequantisation + inverse DCT -----------------------------------------------------------------------------------
 // jidctint.c, jpeg_idct_islow: CONST_BITS 13, PASS1_BITS 2; one pass over eight values, arithmetic modulo 2^32
 __device__ __forceinline__ int32_t jmul(int32_t a, int32_t b) { return (int32_t)((uint32_t)a * (uint32_t)b); }
@@ -536,7 +827,8 @@ constexpr int kIdctBlocksPerWg = 32;
 // grid (ceil(frameBlocks / 32), frames).  A frame's planes: component 0 (bw0 * 8 bytes a row), then 1, then 2.
 __global__ __launch_bounds__(256) void k_jpeg_idct(int16_t* __restrict__ coef, const JpegDesc* __restrict__ desc,
                                                    const uint16_t* __restrict__ quant, uint8_t* __restrict__ planes,
-                                                   uint32_t frameBlocks, const int32_t* __restrict__ frameOf) {
+                                                   uint32_t frameBlocks, const int32_t* __restrict__ frameOf,
+                                                   const int16_t* __restrict__ dcs, const int32_t* __restrict__ skip) {
     __shared__ int32_t s_ws[kIdctBlocksPerWg][8 * 9];
     const int f = frameOf ? frameOf[blockIdx.y] : (int)blockIdx.y;
     const JpegDesc d = desc[f];
@@ -553,7 +845,14 @@ __global__ __launch_bounds__(256) void k_jpeg_idct(int16_t* __restrict__ coef, c
     const uint4 cv = *cp;
     *cp = make_uint4(0, 0, 0, 0);  // (the coefficient planes are all zero between calls: k_jpeg_huff stores only what is not)
     const uint4 qv = *reinterpret_cast<const uint4*>(quant + ((size_t)f * 4 + (c == 0 ? d.tq[0] : c == 1 ? d.tq[1] : d.tq[2])) * 64 + r * 8);
-    const uint32_t cw[4] = {cv.x, cv.y, cv.z, cv.w}, qw[4] = {qv.x, qv.y, qv.z, qv.w};
+    uint32_t cw[4] = {cv.x, cv.y, cv.z, cv.w};
+    const uint32_t qw[4] = {qv.x, qv.y, qv.z, qv.w};
+    if (r == 0 && dcs && !skip[f]) {
+        // the parallel entropy decoder keeps the DC coefficients apart, a component's blocks in the order they are coded
+        const uint32_t hc = c == 0 ? d.hmax : 1u, vc = c == 0 ? d.vmax : 1u;
+        const uint32_t m = (brow / vc) * d.mcux + bcol / hc, at = m * hc * vc + (brow % vc) * hc + bcol % hc;
+        cw[0] = (cw[0] & 0xFFFF0000u) | (uint16_t)dcs[(size_t)f * frameBlocks + (c == 0 ? 0u : c == 1 ? n0 : n0 + n1) + at];
+    }
     int32_t* const ws = s_ws[g];
     // this lane holds the coefficients coded 8 r-th .. 8 r + 7-th and their quantisation steps (both in coding order)
     const uint2 zz = *reinterpret_cast<const uint2*>(&c_zigzag9[r * 8]);
@@ -862,6 +1161,13 @@ struct JpegState {
     int16_t* d_coef = nullptr; size_t coefCap = 0;   // [frames][frameBlocks][64], all zero between calls
     uint8_t* d_planes = nullptr; size_t planesCap = 0;
     uint8_t* d_out = nullptr; size_t outCap = 0;      // BGR frames when the caller's output is on the host
+    // the parallel entropy decoder (k_jpeg_unstuff / k_jpeg_par / k_jpeg_dc)
+    uint8_t* d_ubytes = nullptr; size_t ubytesCap = 0;            // the frames' streams without byte stuffing
+    unsigned long long* d_rec = nullptr; size_t recCap = 0;      // a record per subsequence
+    unsigned long long* d_last = nullptr; size_t lastCap = 0;    // the entry state a record was computed from
+    int32_t* d_parMeta = nullptr; size_t parMetaCap = 0;         // per frame / per workgroup index arrays, packed
+    int32_t* d_changed = nullptr; size_t changedCap = 0;         // [0] any record changed, [1 + f] the last round frame f's did
+    int16_t* d_dcs = nullptr; size_t dcsCap = 0;                  // DC coefficients [frames][frameBlocks], in coding order
     bool coefDirty = false;
 };
 
@@ -869,7 +1175,8 @@ JpegState* jpeg_create() { return new JpegState(); }
 
 void jpeg_destroy(JpegState* s) {
     if (!s) return;
-    void* ptrs[] = {s->d_bytes, s->d_desc, s->d_quant, s->d_tables, s->d_groups, s->d_status, s->d_coef, s->d_planes, s->d_out};
+    void* ptrs[] = {s->d_bytes, s->d_desc, s->d_quant, s->d_tables, s->d_groups, s->d_status, s->d_coef, s->d_planes, s->d_out,
+                    s->d_ubytes, s->d_rec, s->d_last, s->d_parMeta, s->d_changed, s->d_dcs};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (s->h_bytes) (void)hipHostFree(s->h_bytes);
@@ -961,30 +1268,71 @@ int jpeg_decode_batch(JpegState* s, hipStream_t st, const uint8_t* const* jpegs,
             }
             framesOfSet[(size_t)it->second].push_back(i);
         }
-        // frames with at most two DC and two AC tables take a wavefront each (k_jpeg_huff_wave); the others share
-        // wavefronts, kHuffLanes frames of one table set to each (k_jpeg_huff)
-        groups.clear();
-        std::vector<int32_t> waveList;
-        for (size_t set = 0; set < framesOfSet.size(); set++) {
-            std::vector<int> shared;
-            for (int i : framesOfSet[set]) {
-                if (!pf[(size_t)i].dc[2].set && !pf[(size_t)i].ac[2].set) {
-                    waveList.push_back(i);
-                    waveList.push_back((int32_t)set);
-                } else {
-                    shared.push_back(i);
+        // Frames without restart intervals go to the parallel decoder; the others (and the frames whose records do not
+        // settle there) to the sequential kernels: those with at most two DC and two AC tables take a wavefront each
+        // (k_jpeg_huff_wave), the rest share wavefronts, kHuffLanes frames of one table set to each (k_jpeg_huff).
+        static const bool sequentialOnly = getenv("CAMSYNC_JPEG_SEQUENTIAL") != nullptr;  // (tests: the sequential kernels on every frame)
+        std::vector<int32_t> frameSet((size_t)nb, 0), parList, skip((size_t)nb, 1);
+        for (size_t set = 0; set < framesOfSet.size(); set++)
+            for (int i : framesOfSet[set]) frameSet[(size_t)i] = (int32_t)set;
+        for (int i = 0; i < nb; i++)
+            if (pf[(size_t)i].d.restart == 0 && !sequentialOnly) {
+                parList.push_back(i);
+                skip[(size_t)i] = 0;
+            }
+        int nGroups = 0, nWave = 0;
+        size_t waveOff = 0;
+        auto build_sequential_lists = [&]() {  // from skip[]
+            groups.clear();
+            std::vector<int32_t> waveList;
+            for (size_t set = 0; set < framesOfSet.size(); set++) {
+                std::vector<int> shared;
+                for (int i : framesOfSet[set]) {
+                    if (!skip[(size_t)i]) continue;
+                    if (!pf[(size_t)i].dc[2].set && !pf[(size_t)i].ac[2].set) {
+                        waveList.push_back(i);
+                        waveList.push_back((int32_t)set);
+                    } else {
+                        shared.push_back(i);
+                    }
+                }
+                for (size_t k = 0; k < shared.size(); k += kHuffLanes) {
+                    groups.push_back((int32_t)set);
+                    for (size_t j = 0; j < (size_t)kHuffLanes; j++) groups.push_back(k + j < shared.size() ? shared[k + j] : -1);
                 }
             }
-            for (size_t k = 0; k < shared.size(); k += kHuffLanes) {
-                groups.push_back((int32_t)set);
-                for (size_t j = 0; j < (size_t)kHuffLanes; j++) groups.push_back(k + j < shared.size() ? shared[k + j] : -1);
+            nGroups = (int)(groups.size() / (1 + kHuffLanes));
+            nWave = (int)(waveList.size() / 2);
+            waveOff = groups.size();
+            groups.insert(groups.end(), waveList.begin(), waveList.end());
+            if (groups.empty()) groups.push_back(0);
+        };
+        // the parallel decoder's index arrays: per frame its table set, its first record and the skip flag; per
+        // workgroup of 256 subsequences its frame and its first subsequence
+        std::vector<uint32_t> subBase((size_t)nb, 0), wgFirst;
+        std::vector<int32_t> wgFrame;
+        size_t nRec = 0;
+        for (int i : parList) {
+            const uint32_t nSub = (uint32_t)(((size_t)pf[(size_t)i].d.dataLen * 8 + kParBits - 1) / kParBits);
+            subBase[(size_t)i] = (uint32_t)nRec;
+            nRec += nSub;
+            for (uint32_t k = 0; k < nSub; k += 256) {
+                wgFrame.push_back(i);
+                wgFirst.push_back(k);
             }
         }
-        const int nGroups = (int)(groups.size() / (1 + kHuffLanes));
-        const int nWave = (int)(waveList.size() / 2);
-        const size_t waveOff = groups.size();
-        groups.insert(groups.end(), waveList.begin(), waveList.end());
-        if (groups.empty()) groups.push_back(0);
+        if (nRec > 0xFFFFFFF0ull) { err = "too many subsequences in one pass"; return CAMSYNC_E_ARG; }
+        const size_t nWg = wgFrame.size();
+        // packed: frameSet[nb] | subBase[nb] | skip[nb] | ulenBits[nb] | parList[nb] | wgFrame[nWg] | wgFirst[nWg]
+        std::vector<int32_t> parMeta((size_t)5 * nb + 2 * nWg, 0);
+        memcpy(&parMeta[0], frameSet.data(), (size_t)nb * 4);
+        memcpy(&parMeta[(size_t)nb], subBase.data(), (size_t)nb * 4);
+        memcpy(&parMeta[(size_t)2 * nb], skip.data(), (size_t)nb * 4);
+        if (!parList.empty()) memcpy(&parMeta[(size_t)4 * nb], parList.data(), parList.size() * 4);
+        if (nWg) {
+            memcpy(&parMeta[(size_t)5 * nb], wgFrame.data(), nWg * 4);
+            memcpy(&parMeta[(size_t)5 * nb + nWg], wgFirst.data(), nWg * 4);
+        }
         descs.resize((size_t)nb);
         quant.resize((size_t)nb * 256);
         for (int i = 0; i < nb; i++) {
@@ -1005,7 +1353,10 @@ int jpeg_decode_batch(JpegState* s, hipStream_t st, const uint8_t* const* jpegs,
         const bool freshCoef = coefNeed > s->coefCap;
         if (!regrow_dev(s->d_bytes, s->bytesCap, totalBytes) || !regrow_dev(s->d_desc, s->descCap, (size_t)nb) ||
             !regrow_dev(s->d_quant, s->quantCap, (size_t)nb * 256) || !regrow_dev(s->d_tables, s->tablesCap, tables.size()) ||
-            !regrow_dev(s->d_groups, s->groupsCap, groups.size()) || !regrow_dev(s->d_status, s->statusCap, (size_t)nb) ||
+            !regrow_dev(s->d_groups, s->groupsCap, (size_t)nb * (3 + kHuffLanes) + 1) || !regrow_dev(s->d_status, s->statusCap, (size_t)nb) ||
+            (!parList.empty() && (!regrow_dev(s->d_ubytes, s->ubytesCap, totalBytes) || !regrow_dev(s->d_rec, s->recCap, nRec) ||
+                                  !regrow_dev(s->d_last, s->lastCap, nRec) || !regrow_dev(s->d_dcs, s->dcsCap, (size_t)nb * frameBlocks))) ||
+            !regrow_dev(s->d_parMeta, s->parMetaCap, parMeta.size()) || !regrow_dev(s->d_changed, s->changedCap, (size_t)nb + 1) ||
             !regrow_dev(s->d_coef, s->coefCap, coefNeed) || !regrow_dev(s->d_planes, s->planesCap, (size_t)nb * frameBlocks * 64) ||
             (!outOnDevice && !regrow_dev(s->d_out, s->outCap, (size_t)nb * H * W * 3))) {
             err = "out of device memory for the JPEG decoder's buffers";
@@ -1042,11 +1393,47 @@ int jpeg_decode_batch(JpegState* s, hipStream_t st, const uint8_t* const* jpegs,
         if ((e = hipMemcpyAsync(s->d_desc, descs.data(), sizeof(JpegDesc) * nb, hipMemcpyHostToDevice, st)) != hipSuccess) return hipfail("hipMemcpyAsync", e);
         if ((e = hipMemcpyAsync(s->d_quant, quant.data(), quant.size() * 2, hipMemcpyHostToDevice, st)) != hipSuccess) return hipfail("hipMemcpyAsync", e);
         if ((e = hipMemcpyAsync(s->d_tables, tables.data(), tables.size(), hipMemcpyHostToDevice, st)) != hipSuccess) return hipfail("hipMemcpyAsync", e);
-        if ((e = hipMemcpyAsync(s->d_groups, groups.data(), groups.size() * 4, hipMemcpyHostToDevice, st)) != hipSuccess) return hipfail("hipMemcpyAsync", e);
+        if ((e = hipMemcpyAsync(s->d_parMeta, parMeta.data(), parMeta.size() * 4, hipMemcpyHostToDevice, st)) != hipSuccess) return hipfail("hipMemcpyAsync", e);
         if ((e = hipMemsetAsync(s->d_status, 0, sizeof(int32_t) * nb, st)) != hipSuccess) return hipfail("hipMemsetAsync", e);
-        // ---- the three kernels ----
+        // ---- entropy decoding ----
         uint8_t* const dst = outOnDevice ? out + (size_t)b0 * H * W * 3 : s->d_out;
         s->coefDirty = true;  // (until the inverse DCT has put the zeros back)
+        const int32_t *const d_frameSet = s->d_parMeta, *const d_skip = s->d_parMeta + (size_t)2 * nb, *const d_parList = s->d_parMeta + (size_t)4 * nb,
+                      *const d_wgFrame = s->d_parMeta + (size_t)5 * nb;
+        const uint32_t *const d_subBase = reinterpret_cast<const uint32_t*>(s->d_parMeta + (size_t)nb),
+                       *const d_wgFirst = reinterpret_cast<const uint32_t*>(s->d_parMeta + (size_t)5 * nb + nWg);
+        uint32_t* const d_ulen = reinterpret_cast<uint32_t*>(s->d_parMeta + (size_t)3 * nb);
+        if (!parList.empty()) {
+            if ((e = hipMemsetAsync(s->d_changed, 0, sizeof(int32_t) * ((size_t)nb + 1), st)) != hipSuccess) return hipfail("hipMemsetAsync", e);
+            hipLaunchKernelGGL(k_jpeg_unstuff, dim3((unsigned)parList.size()), dim3(256), 0, st, s->d_bytes, s->d_desc, d_parList, s->d_ubytes,
+                               d_ulen, d_subBase, s->d_rec, s->d_last);
+            bool settled = false;
+            for (int round = 1; round <= kParMaxRounds && !settled; round++) {
+                if ((e = hipMemsetAsync(s->d_changed, 0, sizeof(int32_t), st)) != hipSuccess) return hipfail("hipMemsetAsync", e);
+                hipLaunchKernelGGL((k_jpeg_par<false>), dim3((unsigned)nWg), dim3(256), 0, st, s->d_ubytes, s->d_desc, d_wgFrame, d_wgFirst,
+                                   s->d_tables, d_frameSet, d_ulen, d_subBase, s->d_rec, s->d_last, s->d_changed, round, d_skip, s->d_coef,
+                                   s->d_dcs, frameBlocks, s->d_status);
+                int32_t flag = 0;
+                if ((e = hipMemcpyAsync(&flag, s->d_changed, sizeof flag, hipMemcpyDeviceToHost, st)) != hipSuccess) return hipfail("hipMemcpyAsync", e);
+                if ((e = hipStreamSynchronize(st)) != hipSuccess) return hipfail("JPEG kernels (parallel entropy decoding)", e);
+                settled = flag == 0;
+                if (settled && getenv("CAMSYNC_DEBUG_JPEG")) fprintf(stderr, "jpeg: %zu frames, %zu subsequences settled after %d rounds\n", parList.size(), nRec, round);
+            }
+            if (!settled) {
+                // the frames whose records still changed in the last round take the sequential kernels
+                std::vector<int32_t> last((size_t)nb + 1, 0);
+                if ((e = hipMemcpy(last.data(), s->d_changed, sizeof(int32_t) * ((size_t)nb + 1), hipMemcpyDeviceToHost)) != hipSuccess) return hipfail("hipMemcpy", e);
+                for (int i : parList)
+                    if (last[(size_t)i + 1] == kParMaxRounds) skip[(size_t)i] = 1;
+                if ((e = hipMemcpyAsync(s->d_parMeta + (size_t)2 * nb, skip.data(), (size_t)nb * 4, hipMemcpyHostToDevice, st)) != hipSuccess) return hipfail("hipMemcpyAsync", e);
+            }
+            hipLaunchKernelGGL((k_jpeg_par<true>), dim3((unsigned)nWg), dim3(256), 0, st, s->d_ubytes, s->d_desc, d_wgFrame, d_wgFirst,
+                               s->d_tables, d_frameSet, d_ulen, d_subBase, s->d_rec, s->d_last, s->d_changed, 0, d_skip, s->d_coef, s->d_dcs,
+                               frameBlocks, s->d_status);
+            hipLaunchKernelGGL(k_jpeg_dc, dim3(3, (unsigned)parList.size()), dim3(256), 0, st, s->d_dcs, s->d_desc, d_parList, d_skip, frameBlocks);
+        }
+        build_sequential_lists();
+        if ((e = hipMemcpyAsync(s->d_groups, groups.data(), groups.size() * 4, hipMemcpyHostToDevice, st)) != hipSuccess) return hipfail("hipMemcpyAsync", e);
         if (nGroups)
             hipLaunchKernelGGL(k_jpeg_huff, dim3((unsigned)nGroups), dim3(64), 0, st, s->d_bytes, s->d_desc, s->d_groups, s->d_tables,
                                s->d_coef, frameBlocks, s->d_status);
@@ -1054,7 +1441,8 @@ int jpeg_decode_batch(JpegState* s, hipStream_t st, const uint8_t* const* jpegs,
             hipLaunchKernelGGL(k_jpeg_huff_wave, dim3((unsigned)nWave), dim3(64), 0, st, s->d_bytes, s->d_desc, s->d_groups + waveOff,
                                s->d_tables, s->d_coef, frameBlocks, s->d_status);
         hipLaunchKernelGGL(k_jpeg_idct, dim3((frameBlocks + kIdctBlocksPerWg - 1) / kIdctBlocksPerWg, (unsigned)nb), dim3(256), 0, st,
-                           s->d_coef, s->d_desc, s->d_quant, s->d_planes, frameBlocks, (const int32_t*)nullptr);
+                           s->d_coef, s->d_desc, s->d_quant, s->d_planes, frameBlocks, (const int32_t*)nullptr,
+                           parList.empty() ? (const int16_t*)nullptr : s->d_dcs, d_skip);
         const unsigned colorBlocks = (unsigned)(((size_t)H * ((W + 3) / 4) + 255) / 256);
         hipLaunchKernelGGL(k_jpeg_color, dim3(colorBlocks, (unsigned)nb), dim3(256), 0, st, s->d_planes, s->d_desc, frameBlocks, H, W,
                            dst, (const int32_t*)nullptr);
