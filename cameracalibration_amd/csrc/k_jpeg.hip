@@ -25,6 +25,8 @@
 #include "internal.h"
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cstring>
 #include <map>
 #include <string>
@@ -515,7 +517,7 @@ __global__ __launch_bounds__(64) void k_jpeg_huff_wave(const uint8_t* __restrict
 #define PAR_BITS 1024
 #endif
 constexpr uint32_t kParBits = PAR_BITS;  // a multiple of 32
-constexpr int kParMaxRounds = 64;
+constexpr int kParMaxRounds = 128;
 constexpr unsigned long long kParStateMask = 0xFFFFFFFFFFFFull;  // position | block of the MCU << 32 | coefficient << 40
 
 // One workgroup per frame: the frame's entropy-coded bytes without the stuffed zeros (0xFF 0x00 -> 0xFF), up to the
@@ -901,34 +903,70 @@ __device__ __forceinline__ int chroma_at(const uint8_t* __restrict__ C, int stri
     return (3 * cur + nbr + ((x & 1) ? 7 : 8)) >> 4;
 }
 
-// lane = four pixels of one row; grid (ceil(H * ceil(W / 4) / 256), frames)
+// Eight upsampled chroma values for the pixels x0 .. x0 + 7 of row y (x0 a multiple of 8): the same formulas as
+// chroma_at, with the row's samples fetched as one aligned word and the two bytes next to it instead of byte by byte.
+__device__ __forceinline__ void chroma8(const uint8_t* __restrict__ C, int stride, int cw, int ch, int hmax, int vmax, int x0, int y, int out[8]) {
+    if (hmax == 1) {
+        const uint2 v = *reinterpret_cast<const uint2*>(C + (size_t)y * stride + x0);  // (the plane is padded to whole blocks)
+#pragma unroll
+        for (int t = 0; t < 8; t++) out[t] = (int)(((t < 4 ? v.x : v.y) >> (8 * (t & 3))) & 255u);
+        return;
+    }
+    const int i0 = x0 >> 1, last = cw - 1 - i0;  // (>= 0 for a lane that has pixels)
+    // s[k + 1] = sample i0 + k, k = -1 .. 4, indices clamped into the row
+    auto samples = [&](const uint8_t* row, int s[6]) {
+        const uint32_t w = *reinterpret_cast<const uint32_t*>(row + i0);
+        s[0] = row[max(i0 - 1, 0)];
+#pragma unroll
+        for (int k = 0; k < 4; k++) s[k + 1] = (int)((w >> (8 * min(k, last))) & 255u);
+        s[5] = row[min(i0 + 4, cw - 1)];
+    };
+    int s[6];
+    if (vmax == 1) {
+        samples(C + (size_t)y * stride, s);
+#pragma unroll
+        for (int t = 0; t < 8; t++) out[t] = (3 * s[(t >> 1) + 1] + s[(t >> 1) + ((t & 1) ? 2 : 0)] + ((t & 1) ? 2 : 1)) >> 2;
+        return;
+    }
+    const int j = y >> 1, jn = (y & 1) ? min(j + 1, ch - 1) : max(j - 1, 0);
+    int s1[6];
+    samples(C + (size_t)j * stride, s);
+    samples(C + (size_t)jn * stride, s1);
+#pragma unroll
+    for (int k = 0; k < 6; k++) s[k] = 3 * s[k] + s1[k];
+#pragma unroll
+    for (int t = 0; t < 8; t++) out[t] = (3 * s[(t >> 1) + 1] + s[(t >> 1) + ((t & 1) ? 2 : 0)] + ((t & 1) ? 7 : 8)) >> 4;
+}
+
+// lane = eight pixels of one row; grid (ceil(H * ceil(W / 8) / 256), frames)
 __global__ __launch_bounds__(256) void k_jpeg_color(const uint8_t* __restrict__ planes, const JpegDesc* __restrict__ desc,
                                                     uint32_t frameBlocks, int H, int W, uint8_t* __restrict__ out,
                                                     const int32_t* __restrict__ frameOf) {
     const int f = frameOf ? frameOf[blockIdx.y] : (int)blockIdx.y;
-    const int W4 = (W + 3) >> 2;
+    const int W8 = (W + 7) >> 3;
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
-    if (t >= (uint32_t)(H * W4)) return;
-    const int y = (int)(t / (uint32_t)W4), x0 = (int)(t - (uint32_t)y * W4) * 4;
+    if (t >= (uint32_t)(H * W8)) return;
+    const int y = (int)(t / (uint32_t)W8), x0 = (int)(t - (uint32_t)y * W8) * 8;
     const JpegDesc d = desc[f];
     const uint32_t bw0 = (uint32_t)d.mcux * d.hmax, n0 = bw0 * ((uint32_t)d.mcuy * d.vmax), n1 = (uint32_t)d.mcux * d.mcuy;
     const uint8_t* const Y = planes + (size_t)f * frameBlocks * 64;
     const int ys = (int)bw0 * 8;
-    uint32_t px[4];
-    const uint32_t yw = *reinterpret_cast<const uint32_t*>(Y + (size_t)y * ys + x0);  // (the plane is padded to whole blocks)
+    uint32_t px[8];
+    const uint2 yw = *reinterpret_cast<const uint2*>(Y + (size_t)y * ys + x0);  // (the plane is padded to whole blocks)
     if (d.nc == 1) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) px[i] = ((yw >> (8 * i)) & 255u) * 0x010101u;
+        for (int i = 0; i < 8; i++) px[i] = (((i < 4 ? yw.x : yw.y) >> (8 * (i & 3))) & 255u) * 0x010101u;
     } else {
         const uint8_t* const Cb = Y + (size_t)n0 * 64;
         const uint8_t* const Cr = Cb + (size_t)n1 * 64;
         const int cs = (int)d.mcux * 8, cw = (W + d.hmax - 1) / d.hmax, ch = (H + d.vmax - 1) / d.vmax;
+        int cbv[8], crv[8];
+        chroma8(Cb, cs, cw, ch, d.hmax, d.vmax, x0, y, cbv);
+        chroma8(Cr, cs, cw, ch, d.hmax, d.vmax, x0, y, crv);
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int x = min(x0 + i, W - 1);
-            const int yy = (int)((yw >> (8 * i)) & 255u);
-            const int cb = chroma_at(Cb, cs, cw, ch, d.hmax, d.vmax, x, y) - 128;
-            const int cr = chroma_at(Cr, cs, cw, ch, d.hmax, d.vmax, x, y) - 128;
+        for (int i = 0; i < 8; i++) {
+            const int yy = (int)(((i < 4 ? yw.x : yw.y) >> (8 * (i & 3))) & 255u);
+            const int cb = cbv[i] - 128, cr = crv[i] - 128;
             // jdcolor.c: FIX(1.40200) = 91881, FIX(1.77200) = 116130, FIX(0.71414) = 46802, FIX(0.34414) = 22554
             const uint32_t R = clamp8(yy + ((91881 * cr + 32768) >> 16));
             const uint32_t G = clamp8(yy + ((-22554 * cb + 32768 - 46802 * cr) >> 16));
@@ -938,13 +976,13 @@ __global__ __launch_bounds__(256) void k_jpeg_color(const uint8_t* __restrict__ 
     }
     const size_t pix = (size_t)f * H * W + (size_t)y * W + x0;
     uint8_t* const o = out + pix * 3;
-    if (x0 + 3 < W && (pix & 3u) == 0) {  // (12 bytes, 4-byte aligned when the pixel index is a multiple of 4: `out` is)
-        uint32_t* o32 = reinterpret_cast<uint32_t*>(o);
-        o32[0] = px[0] | (px[1] << 24);
-        o32[1] = (px[1] >> 8) | (px[2] << 16);
-        o32[2] = (px[2] >> 16) | (px[3] << 8);
+    if (x0 + 7 < W && (pix & 7u) == 0) {  // (24 bytes, 8-byte aligned when the pixel index is a multiple of 8: `out` is)
+        uint2* o64 = reinterpret_cast<uint2*>(o);
+        o64[0] = make_uint2(px[0] | (px[1] << 24), (px[1] >> 8) | (px[2] << 16));
+        o64[1] = make_uint2((px[2] >> 16) | (px[3] << 8), px[4] | (px[5] << 24));
+        o64[2] = make_uint2((px[5] >> 8) | (px[6] << 16), (px[6] >> 16) | (px[7] << 8));
     } else {
-        for (int i = 0; i < 4 && x0 + i < W; i++) {
+        for (int i = 0; i < 8 && x0 + i < W; i++) {
             o[3 * i] = (uint8_t)px[i];
             o[3 * i + 1] = (uint8_t)(px[i] >> 8);
             o[3 * i + 2] = (uint8_t)(px[i] >> 16);
@@ -1221,8 +1259,12 @@ int jpeg_decode_batch(JpegState* s, hipStream_t st, const uint8_t* const* jpegs,
     std::vector<JpegDesc> descs;
     std::vector<uint16_t> quant;
     std::vector<int32_t> groups, status;
+    static const bool dbg = getenv("CAMSYNC_DEBUG_JPEG") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     for (int b0 = 0; b0 < B; b0 += chunk) {
         const int nb = std::min(chunk, B - b0);
+        const auto t0 = now();
         pf.assign((size_t)nb, ParsedFrame());
         size_t totalBytes = 0;
         for (int i = 0; i < nb; i++) {
@@ -1339,6 +1381,7 @@ int jpeg_decode_batch(JpegState* s, hipStream_t st, const uint8_t* const* jpegs,
             descs[(size_t)i] = pf[(size_t)i].d;
             memcpy(&quant[(size_t)i * 256], pf[(size_t)i].quant, 512);
         }
+        const auto t1 = now();
         // ---- buffers ----
         if (totalBytes > s->hBytesCap) {
             if (s->h_bytes) (void)hipHostFree(s->h_bytes);
@@ -1367,9 +1410,13 @@ int jpeg_decode_batch(JpegState* s, hipStream_t st, const uint8_t* const* jpegs,
             if ((e = hipMemsetAsync(s->d_coef, 0, s->coefCap * sizeof(int16_t), st)) != hipSuccess) return hipfail("hipMemsetAsync", e);
             s->coefDirty = false;
         }
+        const auto t2 = now();
         // the frames' entropy-coded bytes, packed (16-byte aligned each, zeros in between and after the last): with
         // hundreds of megabytes to move this is a good part of the call, so several threads share it
         {
+            std::atomic<int> copyErr{(int)hipSuccess};
+            int devId = 0;
+            (void)hipGetDevice(&devId);
             auto pack = [&](int i0, int i1) {
                 for (int i = i0; i < i1; i++) {
                     const JpegDesc& d = pf[(size_t)i].d;
@@ -1377,6 +1424,13 @@ int jpeg_decode_batch(JpegState* s, hipStream_t st, const uint8_t* const* jpegs,
                     memcpy(dst, jpegs[b0 + i] + pf[(size_t)i].scanOff, d.dataLen);
                     const size_t end = i + 1 < nb ? pf[(size_t)i + 1].d.dataOff : totalBytes;
                     memset(dst + d.dataLen, 0, end - d.dataOff - d.dataLen);
+                }
+                // each range goes to the device as soon as it is packed (the link works while the others still pack)
+                if (i1 > i0) {
+                    const size_t lo = pf[(size_t)i0].d.dataOff, hi = i1 < nb ? pf[(size_t)i1].d.dataOff : totalBytes;
+                    hipError_t ce = hipSetDevice(devId);
+                    if (ce == hipSuccess) ce = hipMemcpyAsync(s->d_bytes + lo, s->h_bytes + lo, hi - lo, hipMemcpyHostToDevice, st);
+                    if (ce != hipSuccess) copyErr = (int)ce;
                 }
             };
             const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
@@ -1388,8 +1442,9 @@ int jpeg_decode_batch(JpegState* s, hipStream_t st, const uint8_t* const* jpegs,
                 for (int t = 0; t < nt; t++) th.emplace_back(pack, (int)((long long)nb * t / nt), (int)((long long)nb * (t + 1) / nt));
                 for (auto& x : th) x.join();
             }
+            if (copyErr.load() != (int)hipSuccess) return hipfail("hipMemcpyAsync(compressed frames)", (hipError_t)copyErr.load());
         }
-        if ((e = hipMemcpyAsync(s->d_bytes, s->h_bytes, totalBytes, hipMemcpyHostToDevice, st)) != hipSuccess) return hipfail("hipMemcpyAsync", e);
+        const auto t3 = now();
         if ((e = hipMemcpyAsync(s->d_desc, descs.data(), sizeof(JpegDesc) * nb, hipMemcpyHostToDevice, st)) != hipSuccess) return hipfail("hipMemcpyAsync", e);
         if ((e = hipMemcpyAsync(s->d_quant, quant.data(), quant.size() * 2, hipMemcpyHostToDevice, st)) != hipSuccess) return hipfail("hipMemcpyAsync", e);
         if ((e = hipMemcpyAsync(s->d_tables, tables.data(), tables.size(), hipMemcpyHostToDevice, st)) != hipSuccess) return hipfail("hipMemcpyAsync", e);
@@ -1407,17 +1462,24 @@ int jpeg_decode_batch(JpegState* s, hipStream_t st, const uint8_t* const* jpegs,
             if ((e = hipMemsetAsync(s->d_changed, 0, sizeof(int32_t) * ((size_t)nb + 1), st)) != hipSuccess) return hipfail("hipMemsetAsync", e);
             hipLaunchKernelGGL(k_jpeg_unstuff, dim3((unsigned)parList.size()), dim3(256), 0, st, s->d_bytes, s->d_desc, d_parList, s->d_ubytes,
                                d_ulen, d_subBase, s->d_rec, s->d_last);
+            // rounds until one changes nothing; the host only looks after some of them (a round in which few lanes have work
+            // is a few microseconds, waiting for the stream is more)
             bool settled = false;
+            static const int kLook[] = {3, 5, 8, 12, 16, 24, 32, 48, 64, 96, kParMaxRounds};
+            int look = 0;
             for (int round = 1; round <= kParMaxRounds && !settled; round++) {
-                if ((e = hipMemsetAsync(s->d_changed, 0, sizeof(int32_t), st)) != hipSuccess) return hipfail("hipMemsetAsync", e);
+                const bool check = round == kLook[look];
+                if (check && (e = hipMemsetAsync(s->d_changed, 0, sizeof(int32_t), st)) != hipSuccess) return hipfail("hipMemsetAsync", e);
                 hipLaunchKernelGGL((k_jpeg_par<false>), dim3((unsigned)nWg), dim3(256), 0, st, s->d_ubytes, s->d_desc, d_wgFrame, d_wgFirst,
                                    s->d_tables, d_frameSet, d_ulen, d_subBase, s->d_rec, s->d_last, s->d_changed, round, d_skip, s->d_coef,
                                    s->d_dcs, frameBlocks, s->d_status);
+                if (!check) continue;
+                look++;
                 int32_t flag = 0;
                 if ((e = hipMemcpyAsync(&flag, s->d_changed, sizeof flag, hipMemcpyDeviceToHost, st)) != hipSuccess) return hipfail("hipMemcpyAsync", e);
                 if ((e = hipStreamSynchronize(st)) != hipSuccess) return hipfail("JPEG kernels (parallel entropy decoding)", e);
                 settled = flag == 0;
-                if (settled && getenv("CAMSYNC_DEBUG_JPEG")) fprintf(stderr, "jpeg: %zu frames, %zu subsequences settled after %d rounds\n", parList.size(), nRec, round);
+                if (settled && getenv("CAMSYNC_DEBUG_JPEG")) fprintf(stderr, "jpeg: %zu frames, %zu subsequences settled within %d rounds\n", parList.size(), nRec, round);
             }
             if (!settled) {
                 // the frames whose records still changed in the last round take the sequential kernels
@@ -1443,7 +1505,7 @@ int jpeg_decode_batch(JpegState* s, hipStream_t st, const uint8_t* const* jpegs,
         hipLaunchKernelGGL(k_jpeg_idct, dim3((frameBlocks + kIdctBlocksPerWg - 1) / kIdctBlocksPerWg, (unsigned)nb), dim3(256), 0, st,
                            s->d_coef, s->d_desc, s->d_quant, s->d_planes, frameBlocks, (const int32_t*)nullptr,
                            parList.empty() ? (const int16_t*)nullptr : s->d_dcs, d_skip);
-        const unsigned colorBlocks = (unsigned)(((size_t)H * ((W + 3) / 4) + 255) / 256);
+        const unsigned colorBlocks = (unsigned)(((size_t)H * ((W + 7) / 8) + 255) / 256);
         hipLaunchKernelGGL(k_jpeg_color, dim3(colorBlocks, (unsigned)nb), dim3(256), 0, st, s->d_planes, s->d_desc, frameBlocks, H, W,
                            dst, (const int32_t*)nullptr);
         if ((e = hipGetLastError()) != hipSuccess) return hipfail("JPEG kernels", e);
@@ -1452,6 +1514,7 @@ int jpeg_decode_batch(JpegState* s, hipStream_t st, const uint8_t* const* jpegs,
         if (!outOnDevice)
             if ((e = hipMemcpyAsync(out + (size_t)b0 * H * W * 3, s->d_out, (size_t)nb * H * W * 3, hipMemcpyDeviceToHost, st)) != hipSuccess) return hipfail("hipMemcpyAsync", e);
         if ((e = hipStreamSynchronize(st)) != hipSuccess) return hipfail("hipStreamSynchronize", e);
+        if (dbg) fprintf(stderr, "jpeg: %d frames: headers and tables %.2f ms, buffers %.2f ms, packing %.2f ms, device %.2f ms\n", nb, ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, now()));
         s->coefDirty = false;  // every block the Huffman kernel may have touched has been through k_jpeg_idct
         for (int i = 0; i < nb; i++)
             if (status[(size_t)i]) {

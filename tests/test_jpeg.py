@@ -168,6 +168,9 @@ def test_gpu_decodes_every_supported_kind_like_the_oracle(hw):
     datas += [_encode(_scene(hw[0], hw[1], s), quality=70 + s, subsampling=s % 3) for s in range(70)]
     # frames with three Huffman tables per class (the shared-wave kernel), more than one wave of them
     datas += [third_tables(_encode(_scene(hw[0], hw[1], 100 + s), quality=60 + s, subsampling=s % 3)) for s in range(9)]
+    # ... and with restart intervals as well: these go to the kernel that shares a wavefront among frames
+    datas += [third_tables(_encode(_scene(hw[0], hw[1], 200 + s), quality=65 + s, subsampling=s % 3, restart_marker_blocks=3 + s))
+              for s in range(5)]
     ctx = _hip.Context(max(hw[0], 32), max(hw[1], 32), 8)
     got = ctx.decode_jpeg(datas)
     for i, d in enumerate(datas):
@@ -178,6 +181,30 @@ def test_gpu_decodes_every_supported_kind_like_the_oracle(hw):
     assert ctx.decode_jpeg(datas, d_bgr_ptr=dev.data_ptr()) == (len(datas),) + hw + (3,)
     torch.cuda.synchronize()
     assert np.array_equal(dev.cpu().numpy(), got)
+
+
+@pytest.mark.gpu
+def test_gpu_frames_whose_speculative_decoders_do_not_fall_into_step():
+    """The parallel entropy decoder relies on decoders that start anywhere in the stream falling into step with the real
+    one.  In a flat frame every MCU is the same few bits, a decoder that starts out of phase stays out of phase, and the
+    true states only spread one subsequence per round: such frames are handed to the sequential kernels after a
+    bounded number of rounds.  Flat and striped frames, alone and mixed with ordinary ones, against the oracle."""
+    from cameracalibration_amd import _hip
+    h, w = 1080, 1920
+    flat = np.full((h, w, 3), 97, np.uint8)
+    stripes = np.zeros((h, w, 3), np.uint8)
+    stripes[:, ::16] = 255
+    half = _scene(h, w, 9)
+    half[:, w // 2:] = 40
+    datas = [_encode(flat, quality=50, subsampling=1), _encode(flat, quality=90, subsampling=2), _encode(flat, quality=75, subsampling=0),
+             _encode(stripes, quality=80, subsampling=1), _encode(half, quality=85, subsampling=1), _encode(flat[..., 0], quality=60),
+             strip_dht(_encode(_scene(h, w, 10), quality=85, subsampling=1))]
+    ctx = _hip.Context(h, w, 8)
+    got = ctx.decode_jpeg(datas)
+    for i, d in enumerate(datas):
+        assert np.array_equal(got[i], orc.jpeg_decode(d)), i
+    one = ctx.decode_jpeg(datas[:1])
+    assert np.array_equal(one[0], got[0])
 
 
 @pytest.mark.gpu
