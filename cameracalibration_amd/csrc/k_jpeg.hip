@@ -3,21 +3,25 @@
 // them to the reference (camera_sync/camera.py:98-118, 150-154; both end in libjpeg-turbo with its defaults:
 // accurate integer IDCT, triangle-filter chroma upsampling, 16-bit fixed-point YCbCr -> RGB).
 //
-// Three stages per batch:
-//   k_jpeg_huff_wave, k_jpeg_huff   entropy decoding (ITU T.81 Annex F).  A frame's Huffman stream is sequential.
-//                 k_jpeg_huff_wave gives a frame a wavefront: every lane decodes the symbol that would start at its
-//                 bit offset of a 64-bit window, the real symbols are the chain from offset 0 (see the kernel).
-//                 k_jpeg_huff (frames with more than two Huffman tables of a class) gives a frame a lane, a few
-//                 frames of one table set to a wavefront, one symbol per iteration whatever block or coefficient a
-//                 lane is at.  Both store the coefficients straight into the frame's coefficient planes, in coding
-//                 order; the planes are all zero between calls.
+// Stages per batch:
+//   entropy decoding (ITU T.81 Annex F).  A frame's Huffman stream is sequential, but a decoder that enters it anywhere
+//                 falls into step with the real one after a while: k_jpeg_unstuff removes the byte stuffing,
+//                 k_jpeg_par gives every 1024-bit subsequence of a frame a lane and iterates until each lane's entry
+//                 state is the exit state of the lane before it, then decodes once more and stores the coefficients,
+//                 k_jpeg_dc sums the DC differences (see "many lanes per frame" below).  Frames with restart intervals
+//                 and frames that do not settle take the sequential kernels: k_jpeg_huff_wave gives a frame a wavefront
+//                 (every lane decodes the symbol that would start at its bit offset of a 64-bit window, the real symbols
+//                 are the chain from offset 0), k_jpeg_huff (more than two Huffman tables of a class) a lane, a few frames
+//                 of one table set to a wavefront.  All store the coefficients straight into the frame's coefficient
+//                 planes, in coding order; the planes are all zero between calls.
 //   k_jpeg_idct   dequantisation + inverse DCT (jidctint.c's two passes, 32-bit) of every block: eight lanes per block,
 //                 a row of coefficients each (coalesced 16-byte loads), transposed through LDS for the column pass;
 //                 writes the component planes and puts the zeros back into the coefficient planes.
-//   k_jpeg_color  chroma upsampling (h2v1 / h2v2 triangle filters, or none) + colour conversion + BGR packing, four
+//   k_jpeg_color  chroma upsampling (h2v1 / h2v2 triangle filters, or none) + colour conversion + BGR packing, eight
 //                 pixels per lane.
-// Bound: the Huffman kernels by the chain of dependent steps from one symbol to the next (≈ 350 cycles per symbol with a
-// wavefront per frame), the other two by HBM (128 B + 128 B + 64 B per block; 1.5-3 B + 3 B per pixel).
+// Bound: 4096 1080p frames (1 GB compressed) take 100 ms: 18 ms the link, ~32 ms entropy decoding (instruction issue:
+// five passes over the stream, a lane per subsequence), ~20 ms the inverse DCT and ~12 ms the colour conversion (HBM:
+// 128 B + 128 B + 64 B per block; 1.5-3 B + 3 B per pixel).  One frame: 1.3 ms.
 //
 // Scope (the host parser refuses the rest with CAMSYNC_E_ARG): SOF0 / SOF1, 8-bit, one interleaved scan, 1 or 3
 // components (Y / YCbCr), luma sampling 1x1, 2x1 or 2x2 with 1x1 chroma, restart intervals, frames without DHT
@@ -769,22 +773,32 @@ __global__ __launch_bounds__(256) void k_jpeg_dc(int16_t* __restrict__ dcs, cons
     const uint32_t n0 = (uint32_t)d.mcux * d.hmax * ((uint32_t)d.mcuy * d.vmax), n1 = (uint32_t)d.mcux * d.mcuy;
     const uint32_t nblk = c == 0 ? n0 : n1;
     int16_t* const v = dcs + (size_t)f * frameBlocks + (c == 0 ? 0u : c == 1 ? n0 : n0 + n1);
-    const uint32_t per = (nblk + 255u) / 256u, lo = min((uint32_t)tid * per, nblk), hi = min(lo + per, nblk);
-    int32_t sum = 0;
-    for (uint32_t b = lo; b < hi; b++) sum += v[b];
-    int32_t inc = sum;
+    // tiles of 2048 values, eight consecutive ones a lane (a wavefront reads a kilobyte in one piece)
+    int32_t carry = 0;  // uniform: the sum of the tiles before
+    for (uint32_t base = 0; base < nblk; base += 2048u) {
+        const uint32_t at = base + 8u * (uint32_t)tid;
+        int32_t p[8];
+        int32_t sum = 0;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int32_t t = __shfl_up(inc, o);
-        if (lane >= o) inc += t;
-    }
-    if (lane == 63) s_wave[wave] = inc;
-    __syncthreads();
-    int32_t run = inc - sum;
-    for (int k = 0; k < wave; k++) run += s_wave[k];
-    for (uint32_t b = lo; b < hi; b++) {
-        run += v[b];
-        v[b] = (int16_t)run;
+        for (int k = 0; k < 8; k++) {
+            sum += at + (uint32_t)k < nblk ? (int32_t)v[at + k] : 0;
+            p[k] = sum;
+        }
+        int32_t inc = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int32_t t = __shfl_up(inc, o);
+            if (lane >= o) inc += t;
+        }
+        if (lane == 63) s_wave[wave] = inc;
+        __syncthreads();
+        int32_t off = carry + inc - sum;
+        for (int k = 0; k < wave; k++) off += s_wave[k];
+        carry += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if (at + (uint32_t)k < nblk) v[at + k] = (int16_t)(off + p[k]);
+        __syncthreads();
     }
 }
 
