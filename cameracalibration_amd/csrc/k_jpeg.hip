@@ -1220,6 +1220,8 @@ struct JpegState {
     int32_t* d_parMeta = nullptr; size_t parMetaCap = 0;         // per frame / per workgroup index arrays, packed
     int32_t* d_changed = nullptr; size_t changedCap = 0;         // [0] any record changed, [1 + f] the last round frame f's did
     int16_t* d_dcs = nullptr; size_t dcsCap = 0;                  // DC coefficients [frames][frameBlocks], in coding order
+    hipStream_t copySt = nullptr;                                 // the compressed bytes of the next pass travel on this stream
+    hipEvent_t evUp[2] = {};                                      // ... and these say when they have arrived
     bool coefDirty = false;
 };
 
@@ -1232,6 +1234,9 @@ void jpeg_destroy(JpegState* s) {
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (s->h_bytes) (void)hipHostFree(s->h_bytes);
+    for (hipEvent_t e : s->evUp)
+        if (e) (void)hipEventDestroy(e);
+    if (s->copySt) (void)hipStreamDestroy(s->copySt);
     delete s;
 }
 
@@ -1266,35 +1271,119 @@ int jpeg_decode_batch(JpegState* s, hipStream_t st, const uint8_t* const* jpegs,
     };
     const uint32_t maxBW = 2u * (uint32_t)((W + 15) / 16), maxBH = 2u * (uint32_t)((H + 15) / 16);
     const size_t frameCoefBytes = (size_t)3u * maxBW * maxBH * 128;  // (4:4:4, the largest of the supported samplings)
-    // frames per pass: the coefficient planes of a pass stay under 48 GB (the Huffman kernel's time hardly depends on
-    // how many frames it decodes side by side, so a pass takes as many as fit)
-    const int chunk = (int)std::max<size_t>(64, std::min<size_t>((size_t)B, ((size_t)48 << 30) / frameCoefBytes));
-    std::vector<ParsedFrame> pf;
+    // frames per pass: the coefficient planes of a pass stay under 48 GB; a large batch is cut into four passes so that
+    // the compressed bytes of the next pass are packed and sent while the kernels of this one run
+    const size_t fit = std::max<size_t>(64, ((size_t)48 << 30) / frameCoefBytes);
+    const int chunk = (int)std::min<size_t>(fit, B >= 256 ? (size_t)(B + 3) / 4 : (size_t)B);
+    const int nPass = (B + chunk - 1) / chunk;
+    std::vector<ParsedFrame> pfAll((size_t)B), pf;
     std::vector<JpegDesc> descs;
     std::vector<uint16_t> quant;
     std::vector<int32_t> groups, status;
     static const bool dbg = getenv("CAMSYNC_DEBUG_JPEG") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-    for (int b0 = 0; b0 < B; b0 += chunk) {
-        const int nb = std::min(chunk, B - b0);
-        const auto t0 = now();
-        pf.assign((size_t)nb, ParsedFrame());
+    // ---- headers of all frames; where each frame's entropy-coded bytes lie in its pass's buffer ----
+    const auto tParse = now();
+    std::vector<size_t> passBytes((size_t)nPass, 0);
+    size_t regionBytes = 0;
+    for (int k = 0; k < nPass; k++) {
+        const int b0 = k * chunk, nb = std::min(chunk, B - b0);
         size_t totalBytes = 0;
         for (int i = 0; i < nb; i++) {
-            const char* e = parse_frame(jpegs[b0 + i], sizes[b0 + i], H, W, pf[(size_t)i]);
+            ParsedFrame& f = pfAll[(size_t)(b0 + i)];
+            const char* e = parse_frame(jpegs[b0 + i], sizes[b0 + i], H, W, f);
             if (e) {
                 char tmp[256];
                 snprintf(tmp, sizeof tmp, "frame %d: %s", b0 + i, e);
                 err = tmp;
                 return CAMSYNC_E_ARG;
             }
-            pf[(size_t)i].d.dataOff = (uint32_t)totalBytes;
-            pf[(size_t)i].d.dataLen = (uint32_t)(sizes[b0 + i] - pf[(size_t)i].scanOff);
-            totalBytes += (pf[(size_t)i].d.dataLen + 15u) & ~(size_t)15u;
+            f.d.dataOff = (uint32_t)totalBytes;
+            f.d.dataLen = (uint32_t)(sizes[b0 + i] - f.scanOff);
+            totalBytes += (f.d.dataLen + 15u) & ~(size_t)15u;
             if (totalBytes > 0xFFFF0000ull) { err = "more than 4 GiB of compressed data in one pass"; return CAMSYNC_E_ARG; }
         }
         totalBytes += kHuffWindow + 64;  // (a lane's window is loaded whole, wherever its stream ends)
+        totalBytes = (totalBytes + 255) & ~(size_t)255;
+        passBytes[(size_t)k] = totalBytes;
+        regionBytes = std::max(regionBytes, totalBytes);
+    }
+    // two regions: the pass being decoded and the one being sent
+    const size_t nRegions = nPass > 1 ? 2 : 1;
+    if (nRegions * regionBytes > s->hBytesCap) {
+        if (s->h_bytes) (void)hipHostFree(s->h_bytes);
+        s->h_bytes = nullptr;
+        s->hBytesCap = 0;
+        const size_t n = nRegions * regionBytes + nRegions * regionBytes / 4;
+        hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&s->h_bytes), n, hipHostMallocDefault);
+        if (e != hipSuccess) return hipfail("hipHostMalloc(compressed frames)", e);
+        s->hBytesCap = n;
+    }
+    if (!regrow_dev(s->d_bytes, s->bytesCap, nRegions * regionBytes)) {
+        err = "out of device memory for the JPEG decoder's buffers";
+        return CAMSYNC_E_HIP;
+    }
+    if (!s->copySt) {
+        hipError_t e = hipStreamCreateWithFlags(&s->copySt, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&s->evUp[0], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&s->evUp[1], hipEventDisableTiming);
+        if (e != hipSuccess) return hipfail("stream for the compressed frames", e);
+    }
+    if (dbg) fprintf(stderr, "jpeg: %d frames in %d passes: headers %.2f ms\n", B, nPass, ms(tParse, now()));
+    // The entropy-coded bytes of pass k, packed (16-byte aligned each, zeros in between and after the last) into region
+    // k % 2 of the page-locked buffer by several threads; each sends its range as soon as it is packed.  (With hundreds
+    // of megabytes to move this is a good part of the call.)
+    int devId = 0;
+    (void)hipGetDevice(&devId);
+    auto send_pass = [&](int k) -> int {
+        const int b0 = k * chunk, nb = std::min(chunk, B - b0);
+        const size_t totalBytes = passBytes[(size_t)k], region = (size_t)(k & 1) * regionBytes;
+        std::atomic<int> copyErr{(int)hipSuccess};
+        auto pack = [&](int i0, int i1) {
+            for (int i = i0; i < i1; i++) {
+                const ParsedFrame& f = pfAll[(size_t)(b0 + i)];
+                uint8_t* dst = s->h_bytes + region + f.d.dataOff;
+                memcpy(dst, jpegs[b0 + i] + f.scanOff, f.d.dataLen);
+                const size_t end = i + 1 < nb ? pfAll[(size_t)(b0 + i + 1)].d.dataOff : totalBytes;
+                memset(dst + f.d.dataLen, 0, end - f.d.dataOff - f.d.dataLen);
+            }
+            if (i1 > i0) {
+                const size_t lo = pfAll[(size_t)(b0 + i0)].d.dataOff, hi = i1 < nb ? pfAll[(size_t)(b0 + i1)].d.dataOff : totalBytes;
+                hipError_t ce = hipSetDevice(devId);
+                if (ce == hipSuccess) ce = hipMemcpyAsync(s->d_bytes + region + lo, s->h_bytes + region + lo, hi - lo, hipMemcpyHostToDevice, s->copySt);
+                if (ce != hipSuccess) copyErr = (int)ce;
+            }
+        };
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        const int nt = totalBytes < ((size_t)32 << 20) ? 1 : (int)std::min<unsigned>(std::min<unsigned>(hw, 8u), (unsigned)nb);
+        if (nt <= 1) {
+            pack(0, nb);
+        } else {
+            std::vector<std::thread> th;
+            for (int t = 0; t < nt; t++) th.emplace_back(pack, (int)((long long)nb * t / nt), (int)((long long)nb * (t + 1) / nt));
+            for (auto& x : th) x.join();
+        }
+        if (copyErr.load() != (int)hipSuccess) return hipfail("hipMemcpyAsync(compressed frames)", (hipError_t)copyErr.load());
+        hipError_t e = hipEventRecord(s->evUp[k & 1], s->copySt);
+        if (e != hipSuccess) return hipfail("hipEventRecord", e);
+        return CAMSYNC_OK;
+    };
+    {
+        const int rc0 = send_pass(0);
+        if (rc0) return rc0;
+    }
+    for (int b0 = 0, pass = 0; b0 < B; b0 += chunk, pass++) {
+        const int nb = std::min(chunk, B - b0);
+        const auto t0 = now();
+        // (region (pass + 1) % 2 is free: the pass that used it has been waited for)
+        if (pass + 1 < nPass) {
+            const int rcn = send_pass(pass + 1);
+            if (rcn) return rcn;
+        }
+        pf.assign(pfAll.begin() + b0, pfAll.begin() + b0 + nb);
+        const size_t totalBytes = passBytes[(size_t)pass];
+        const uint8_t* const dBytes = s->d_bytes + (size_t)(pass & 1) * regionBytes;
         // blocks per frame of this pass: the largest of its frames' layouts
         uint32_t frameBlocks = 0;
         for (int i = 0; i < nb; i++) {
@@ -1397,18 +1486,9 @@ int jpeg_decode_batch(JpegState* s, hipStream_t st, const uint8_t* const* jpegs,
         }
         const auto t1 = now();
         // ---- buffers ----
-        if (totalBytes > s->hBytesCap) {
-            if (s->h_bytes) (void)hipHostFree(s->h_bytes);
-            s->h_bytes = nullptr;
-            s->hBytesCap = 0;
-            const size_t n = totalBytes + totalBytes / 4;
-            hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&s->h_bytes), n, hipHostMallocDefault);
-            if (e != hipSuccess) return hipfail("hipHostMalloc(compressed frames)", e);
-            s->hBytesCap = n;
-        }
         const size_t coefNeed = (size_t)nb * frameBlocks * 64;
         const bool freshCoef = coefNeed > s->coefCap;
-        if (!regrow_dev(s->d_bytes, s->bytesCap, totalBytes) || !regrow_dev(s->d_desc, s->descCap, (size_t)nb) ||
+        if (!regrow_dev(s->d_desc, s->descCap, (size_t)nb) ||
             !regrow_dev(s->d_quant, s->quantCap, (size_t)nb * 256) || !regrow_dev(s->d_tables, s->tablesCap, tables.size()) ||
             !regrow_dev(s->d_groups, s->groupsCap, (size_t)nb * (3 + kHuffLanes) + 1) || !regrow_dev(s->d_status, s->statusCap, (size_t)nb) ||
             (!parList.empty() && (!regrow_dev(s->d_ubytes, s->ubytesCap, totalBytes) || !regrow_dev(s->d_rec, s->recCap, nRec) ||
@@ -1425,39 +1505,7 @@ int jpeg_decode_batch(JpegState* s, hipStream_t st, const uint8_t* const* jpegs,
             s->coefDirty = false;
         }
         const auto t2 = now();
-        // the frames' entropy-coded bytes, packed (16-byte aligned each, zeros in between and after the last): with
-        // hundreds of megabytes to move this is a good part of the call, so several threads share it
-        {
-            std::atomic<int> copyErr{(int)hipSuccess};
-            int devId = 0;
-            (void)hipGetDevice(&devId);
-            auto pack = [&](int i0, int i1) {
-                for (int i = i0; i < i1; i++) {
-                    const JpegDesc& d = pf[(size_t)i].d;
-                    uint8_t* dst = s->h_bytes + d.dataOff;
-                    memcpy(dst, jpegs[b0 + i] + pf[(size_t)i].scanOff, d.dataLen);
-                    const size_t end = i + 1 < nb ? pf[(size_t)i + 1].d.dataOff : totalBytes;
-                    memset(dst + d.dataLen, 0, end - d.dataOff - d.dataLen);
-                }
-                // each range goes to the device as soon as it is packed (the link works while the others still pack)
-                if (i1 > i0) {
-                    const size_t lo = pf[(size_t)i0].d.dataOff, hi = i1 < nb ? pf[(size_t)i1].d.dataOff : totalBytes;
-                    hipError_t ce = hipSetDevice(devId);
-                    if (ce == hipSuccess) ce = hipMemcpyAsync(s->d_bytes + lo, s->h_bytes + lo, hi - lo, hipMemcpyHostToDevice, st);
-                    if (ce != hipSuccess) copyErr = (int)ce;
-                }
-            };
-            const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-            const int nt = totalBytes < ((size_t)32 << 20) ? 1 : (int)std::min<unsigned>(std::min<unsigned>(hw, 8u), (unsigned)nb);
-            if (nt <= 1) {
-                pack(0, nb);
-            } else {
-                std::vector<std::thread> th;
-                for (int t = 0; t < nt; t++) th.emplace_back(pack, (int)((long long)nb * t / nt), (int)((long long)nb * (t + 1) / nt));
-                for (auto& x : th) x.join();
-            }
-            if (copyErr.load() != (int)hipSuccess) return hipfail("hipMemcpyAsync(compressed frames)", (hipError_t)copyErr.load());
-        }
+        if ((e = hipStreamWaitEvent(st, s->evUp[pass & 1], 0)) != hipSuccess) return hipfail("hipStreamWaitEvent", e);
         const auto t3 = now();
         if ((e = hipMemcpyAsync(s->d_desc, descs.data(), sizeof(JpegDesc) * nb, hipMemcpyHostToDevice, st)) != hipSuccess) return hipfail("hipMemcpyAsync", e);
         if ((e = hipMemcpyAsync(s->d_quant, quant.data(), quant.size() * 2, hipMemcpyHostToDevice, st)) != hipSuccess) return hipfail("hipMemcpyAsync", e);
@@ -1474,7 +1522,7 @@ int jpeg_decode_batch(JpegState* s, hipStream_t st, const uint8_t* const* jpegs,
         uint32_t* const d_ulen = reinterpret_cast<uint32_t*>(s->d_parMeta + (size_t)3 * nb);
         if (!parList.empty()) {
             if ((e = hipMemsetAsync(s->d_changed, 0, sizeof(int32_t) * ((size_t)nb + 1), st)) != hipSuccess) return hipfail("hipMemsetAsync", e);
-            hipLaunchKernelGGL(k_jpeg_unstuff, dim3((unsigned)parList.size()), dim3(256), 0, st, s->d_bytes, s->d_desc, d_parList, s->d_ubytes,
+            hipLaunchKernelGGL(k_jpeg_unstuff, dim3((unsigned)parList.size()), dim3(256), 0, st, dBytes, s->d_desc, d_parList, s->d_ubytes,
                                d_ulen, d_subBase, s->d_rec, s->d_last);
             // rounds until one changes nothing; the host only looks after some of them (a round in which few lanes have work
             // is a few microseconds, waiting for the stream is more)
@@ -1511,10 +1559,10 @@ int jpeg_decode_batch(JpegState* s, hipStream_t st, const uint8_t* const* jpegs,
         build_sequential_lists();
         if ((e = hipMemcpyAsync(s->d_groups, groups.data(), groups.size() * 4, hipMemcpyHostToDevice, st)) != hipSuccess) return hipfail("hipMemcpyAsync", e);
         if (nGroups)
-            hipLaunchKernelGGL(k_jpeg_huff, dim3((unsigned)nGroups), dim3(64), 0, st, s->d_bytes, s->d_desc, s->d_groups, s->d_tables,
+            hipLaunchKernelGGL(k_jpeg_huff, dim3((unsigned)nGroups), dim3(64), 0, st, dBytes, s->d_desc, s->d_groups, s->d_tables,
                                s->d_coef, frameBlocks, s->d_status);
         if (nWave)
-            hipLaunchKernelGGL(k_jpeg_huff_wave, dim3((unsigned)nWave), dim3(64), 0, st, s->d_bytes, s->d_desc, s->d_groups + waveOff,
+            hipLaunchKernelGGL(k_jpeg_huff_wave, dim3((unsigned)nWave), dim3(64), 0, st, dBytes, s->d_desc, s->d_groups + waveOff,
                                s->d_tables, s->d_coef, frameBlocks, s->d_status);
         hipLaunchKernelGGL(k_jpeg_idct, dim3((frameBlocks + kIdctBlocksPerWg - 1) / kIdctBlocksPerWg, (unsigned)nb), dim3(256), 0, st,
                            s->d_coef, s->d_desc, s->d_quant, s->d_planes, frameBlocks, (const int32_t*)nullptr,
@@ -1528,7 +1576,7 @@ int jpeg_decode_batch(JpegState* s, hipStream_t st, const uint8_t* const* jpegs,
         if (!outOnDevice)
             if ((e = hipMemcpyAsync(out + (size_t)b0 * H * W * 3, s->d_out, (size_t)nb * H * W * 3, hipMemcpyDeviceToHost, st)) != hipSuccess) return hipfail("hipMemcpyAsync", e);
         if ((e = hipStreamSynchronize(st)) != hipSuccess) return hipfail("hipStreamSynchronize", e);
-        if (dbg) fprintf(stderr, "jpeg: %d frames: headers and tables %.2f ms, buffers %.2f ms, packing %.2f ms, device %.2f ms\n", nb, ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, now()));
+        if (dbg) fprintf(stderr, "jpeg: pass of %d frames: sending the next pass and tables %.2f ms, buffers %.2f ms, device %.2f ms\n", nb, ms(t0, t1), ms(t1, t2), ms(t3, now()));
         s->coefDirty = false;  // every block the Huffman kernel may have touched has been through k_jpeg_idct
         for (int i = 0; i < nb; i++)
             if (status[(size_t)i]) {
