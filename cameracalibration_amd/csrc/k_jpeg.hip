@@ -9,10 +9,11 @@
 //                 k_jpeg_par gives every 1024-bit subsequence of a frame a lane and iterates until each lane's entry
 //                 state is the exit state of the lane before it, then decodes once more and stores the coefficients,
 //                 k_jpeg_dc sums the DC differences (see "many lanes per frame" below).  Frames with restart intervals
-//                 and frames that do not settle take the sequential kernels: k_jpeg_huff_wave gives a frame a wavefront
-//                 (every lane decodes the symbol that would start at its bit offset of a 64-bit window, the real symbols
-//                 are the chain from offset 0), k_jpeg_huff (more than two Huffman tables of a class) a lane, a few frames
-//                 of one table set to a wavefront.  All store the coefficients straight into the frame's coefficient
+//                 and frames that do not settle take the sequential kernels: k_jpeg_huff_wave gives a frame -- or, with
+//                 restart intervals, each run of intervals of a frame -- a wavefront (every lane decodes the symbol that
+//                 would start at its bit offset of a 64-bit window, the real symbols are the chain from offset 0),
+//                 k_jpeg_huff (more than two Huffman tables of a class) a lane, a few frames of one table set to a
+//                 wavefront.  All store the coefficients straight into the frame's coefficient
 //                 planes, in coding order; the planes are all zero between calls.
 //   k_jpeg_idct   dequantisation + inverse DCT (jidctint.c's two passes, 32-bit) of every block: eight lanes per block,
 //                 a row of coefficients each (coalesced 16-byte loads), transposed through LDS for the column pass;
@@ -308,16 +309,20 @@ __device__ __forceinline__ uint32_t huff_symbol(const uint8_t* T, const uint32_t
     return (l + size) | (run << 6) | ((size == 0u ? 1u : 0u) << 10) | (((bad || (isDC && sym > 16u)) ? 1u : 0u) << 11) | ((uint32_t)val << 16);
 }
 
-// list: [n][2] = frame, table set
+// list: [n][kWaveEntry] = frame, table set, first byte of the wave's part of the entropy-coded data, its first MCU, its
+// number of MCUs, the number (0..7) of the first restart marker it meets.  A frame without restart intervals is one
+// part; with them, a part is a run of whole intervals (each starts in a known state: a frame's parts are independent).
+constexpr int kWaveEntry = 6;
 __global__ __launch_bounds__(64) void k_jpeg_huff_wave(const uint8_t* __restrict__ bytes, const JpegDesc* __restrict__ desc,
                                                        const int32_t* __restrict__ list, const uint8_t* __restrict__ tableSets,
                                                        int16_t* __restrict__ coef, uint32_t frameBlocks, int32_t* __restrict__ status) {
     __shared__ __align__(16) uint8_t s_tab[4 * kHuffTableBytes];  // DC slots 0, 1, AC slots 0, 1
     __shared__ __align__(16) uint32_t s_ring[kRingBytes / 4];
     const int lane = threadIdx.x;
-    const int f = list[2 * blockIdx.x];
+    const int32_t* const entry = list + (size_t)kWaveEntry * blockIdx.x;
+    const int f = entry[0];
     {
-        const uint8_t* set = tableSets + (size_t)list[2 * blockIdx.x + 1] * kHuffSetTables * kHuffTableBytes;
+        const uint8_t* set = tableSets + (size_t)entry[1] * kHuffSetTables * kHuffTableBytes;
         uint4* dst = reinterpret_cast<uint4*>(s_tab);
         for (int i = lane; i < 4 * kHuffTableBytes / 16; i += 64) {
             const int t = i / (kHuffTableBytes / 16), r = i - t * (kHuffTableBytes / 16);
@@ -326,8 +331,10 @@ __global__ __launch_bounds__(64) void k_jpeg_huff_wave(const uint8_t* __restrict
     }
     __syncthreads();
     const JpegDesc d = desc[f];
-    const uint8_t* const p = bytes + d.dataOff;
-    const uint32_t limit = d.dataLen;
+    const uint32_t partStart = (uint32_t)entry[2], firstMcu = (uint32_t)entry[3];
+    uint32_t mcusLeft = (uint32_t)entry[4];
+    const uint8_t* const p = bytes + d.dataOff + partStart;
+    const uint32_t limit = d.dataLen - partStart;
     int16_t* const fcoef = coef + (size_t)f * frameBlocks * 64;
     // the limits of lengths 9..16 of the four tables (uniform)
     uint32_t lim[4][8];
@@ -347,11 +354,11 @@ __global__ __launch_bounds__(64) void k_jpeg_huff_wave(const uint8_t* __restrict
     bool atMarker = false;
     int pred0 = 0, pred1 = 0, pred2 = 0;
     int c = 0, bx = 0, by = 0, k = 0;
-    uint32_t mx = 0, my = 0, block = 0;
-    int toRestart = d.restart, nextRst = 0;
-    bool done = false, bad = false, restartNow = false;
-    // (a frame of zeros decodes one symbol per window at worst: a bound on the windows that no stream reaches)
-    uint32_t guard = (n0 + 2u * n1 + 1u) * 80u + 1024u;
+    uint32_t my = firstMcu / d.mcux, mx = firstMcu - my * d.mcux, block = 0;
+    int toRestart = d.restart, nextRst = entry[5];
+    bool done = mcusLeft == 0u, bad = false, restartNow = false;
+    // (a part of zeros decodes one symbol per window at worst: a bound on the windows that no stream reaches)
+    uint32_t guard = (mcusLeft * (uint32_t)(d.nc == 1 ? 1 : d.hmax * d.vmax + 2) + 1u) * 80u + 1024u;
 
     auto refill = [&]() {
         if (atMarker) {  // zeros from here on
@@ -487,7 +494,7 @@ __global__ __launch_bounds__(64) void k_jpeg_huff_wave(const uint8_t* __restrict
                         if (++c == d.nc) {
                             c = 0;
                             if (++mx == d.mcux) { mx = 0; my++; }
-                            if (my == d.mcuy) { done = true; break; }
+                            if (--mcusLeft == 0u) { done = true; break; }
                             if (d.restart && --toRestart == 0) { restartNow = true; break; }
                         }
                     }
@@ -515,8 +522,8 @@ __global__ __launch_bounds__(64) void k_jpeg_huff_wave(const uint8_t* __restrict
 // k_jpeg_par<true> then decodes every subsequence once more from its true entry state, now knowing (prefix sum of the
 // block counts) which block it is in, and stores the coefficients; DC differences are stored as they are coded and
 // summed per component afterwards (k_jpeg_dc).  One 1080p frame: ~1900 lanes instead of one chain of 350 k symbols.
-// Frames with restart intervals, and frames whose records have not settled after kParMaxRounds rounds, take the
-// sequential kernels above.
+// Frames with restart intervals (whose intervals need no guessing: k_jpeg_huff_wave decodes them side by side), and
+// frames whose records have not settled after kParMaxRounds rounds, take the sequential kernels above.
 #ifndef PAR_BITS
 #define PAR_BITS 1024
 #endif
@@ -1336,6 +1343,8 @@ int jpeg_decode_batch(JpegState* s, hipStream_t st, const uint8_t* const* jpegs,
     // of megabytes to move this is a good part of the call.)
     int devId = 0;
     (void)hipGetDevice(&devId);
+    // frames with restart intervals: where each interval starts in the frame's entropy-coded bytes (found while packing)
+    std::vector<std::vector<uint32_t>> ivAll((size_t)B);
     auto send_pass = [&](int k) -> int {
         const int b0 = k * chunk, nb = std::min(chunk, B - b0);
         const size_t totalBytes = passBytes[(size_t)k], region = (size_t)(k & 1) * regionBytes;
@@ -1347,6 +1356,29 @@ int jpeg_decode_batch(JpegState* s, hipStream_t st, const uint8_t* const* jpegs,
                 memcpy(dst, jpegs[b0 + i] + f.scanOff, f.d.dataLen);
                 const size_t end = i + 1 < nb ? pfAll[(size_t)(b0 + i + 1)].d.dataOff : totalBytes;
                 memset(dst + f.d.dataLen, 0, end - f.d.dataOff - f.d.dataLen);
+                if (f.d.restart) {
+                    std::vector<uint32_t>& iv = ivAll[(size_t)(b0 + i)];
+                    iv.assign(1, 0u);
+                    const uint8_t *const q = dst, *const qe = dst + f.d.dataLen, *cur = dst;
+                    while (cur < qe && (cur = static_cast<const uint8_t*>(memchr(cur, 0xFF, (size_t)(qe - cur)))) != nullptr) {
+                        if (cur + 1 >= qe) break;
+                        const uint8_t m = cur[1];
+                        if (m >= 0xD0 && m <= 0xD7) {
+                            if ((uint32_t)(m - 0xD0) != ((uint32_t)(iv.size() - 1) & 7u)) {
+                                iv.clear();  // out of sequence: the frame is decoded in one piece, which reports it
+                                break;
+                            }
+                            iv.push_back((uint32_t)(cur + 2 - q));
+                            cur += 2;
+                        } else if (m == 0x00) {
+                            cur += 2;
+                        } else if (m == 0xFF) {
+                            cur += 1;
+                        } else {
+                            break;  // another marker: the data ends here
+                        }
+                    }
+                }
             }
             if (i1 > i0) {
                 const size_t lo = pfAll[(size_t)(b0 + i0)].d.dataOff, hi = i1 < nb ? pfAll[(size_t)(b0 + i1)].d.dataOff : totalBytes;
@@ -1435,8 +1467,23 @@ int jpeg_decode_batch(JpegState* s, hipStream_t st, const uint8_t* const* jpegs,
                 for (int i : framesOfSet[set]) {
                     if (!skip[(size_t)i]) continue;
                     if (!pf[(size_t)i].dc[2].set && !pf[(size_t)i].ac[2].set) {
-                        waveList.push_back(i);
-                        waveList.push_back((int32_t)set);
+                        // a wavefront per frame, or -- restart intervals start in a known state -- one per run of
+                        // intervals, up to 256 wavefronts a frame
+                        const JpegDesc& d = pf[(size_t)i].d;
+                        const uint32_t totalMcu = (uint32_t)d.mcux * d.mcuy;
+                        const std::vector<uint32_t>& iv = ivAll[(size_t)(b0 + i)];
+                        const uint32_t nIv = d.restart ? (totalMcu + d.restart - 1u) / d.restart : 1u;
+                        if (nIv > 1u && iv.size() == (size_t)nIv) {
+                            const uint32_t per = (nIv + 255u) / 256u;
+                            for (uint32_t t = 0; t < nIv; t += per) {
+                                const uint32_t first = t * d.restart, n = std::min(std::min(per, nIv - t) * (uint32_t)d.restart, totalMcu - first);
+                                const int32_t e6[kWaveEntry] = {i, (int32_t)set, (int32_t)iv[t], (int32_t)first, (int32_t)n, (int32_t)(t & 7u)};
+                                waveList.insert(waveList.end(), e6, e6 + kWaveEntry);
+                            }
+                        } else {
+                            const int32_t e6[kWaveEntry] = {i, (int32_t)set, 0, 0, (int32_t)totalMcu, 0};
+                            waveList.insert(waveList.end(), e6, e6 + kWaveEntry);
+                        }
                     } else {
                         shared.push_back(i);
                     }
@@ -1447,7 +1494,7 @@ int jpeg_decode_batch(JpegState* s, hipStream_t st, const uint8_t* const* jpegs,
                 }
             }
             nGroups = (int)(groups.size() / (1 + kHuffLanes));
-            nWave = (int)(waveList.size() / 2);
+            nWave = (int)(waveList.size() / kWaveEntry);
             waveOff = groups.size();
             groups.insert(groups.end(), waveList.begin(), waveList.end());
             if (groups.empty()) groups.push_back(0);
@@ -1490,7 +1537,7 @@ int jpeg_decode_batch(JpegState* s, hipStream_t st, const uint8_t* const* jpegs,
         const bool freshCoef = coefNeed > s->coefCap;
         if (!regrow_dev(s->d_desc, s->descCap, (size_t)nb) ||
             !regrow_dev(s->d_quant, s->quantCap, (size_t)nb * 256) || !regrow_dev(s->d_tables, s->tablesCap, tables.size()) ||
-            !regrow_dev(s->d_groups, s->groupsCap, (size_t)nb * (3 + kHuffLanes) + 1) || !regrow_dev(s->d_status, s->statusCap, (size_t)nb) ||
+            !regrow_dev(s->d_status, s->statusCap, (size_t)nb) ||
             (!parList.empty() && (!regrow_dev(s->d_ubytes, s->ubytesCap, totalBytes) || !regrow_dev(s->d_rec, s->recCap, nRec) ||
                                   !regrow_dev(s->d_last, s->lastCap, nRec) || !regrow_dev(s->d_dcs, s->dcsCap, (size_t)nb * frameBlocks))) ||
             !regrow_dev(s->d_parMeta, s->parMetaCap, parMeta.size()) || !regrow_dev(s->d_changed, s->changedCap, (size_t)nb + 1) ||
@@ -1557,6 +1604,10 @@ int jpeg_decode_batch(JpegState* s, hipStream_t st, const uint8_t* const* jpegs,
             hipLaunchKernelGGL(k_jpeg_dc, dim3(3, (unsigned)parList.size()), dim3(256), 0, st, s->d_dcs, s->d_desc, d_parList, d_skip, frameBlocks);
         }
         build_sequential_lists();
+        if (!regrow_dev(s->d_groups, s->groupsCap, groups.size())) {
+            err = "out of device memory for the JPEG decoder's buffers";
+            return CAMSYNC_E_HIP;
+        }
         if ((e = hipMemcpyAsync(s->d_groups, groups.data(), groups.size() * 4, hipMemcpyHostToDevice, st)) != hipSuccess) return hipfail("hipMemcpyAsync", e);
         if (nGroups)
             hipLaunchKernelGGL(k_jpeg_huff, dim3((unsigned)nGroups), dim3(64), 0, st, dBytes, s->d_desc, s->d_groups, s->d_tables,

@@ -208,6 +208,31 @@ def test_gpu_frames_whose_speculative_decoders_do_not_fall_into_step():
 
 
 @pytest.mark.gpu
+def test_gpu_frames_with_restart_intervals_decode_in_parts():
+    """Restart intervals start in a known state, so a frame's intervals are decoded by up to 256 wavefronts side by
+    side (runs of whole intervals each): intervals of one MCU, of a few, of one and of several MCU rows, more intervals
+    than wavefronts, the last interval short; 4:2:0, 4:2:2, 4:4:4 and gray."""
+    from cameracalibration_amd import _hip
+    h, w = 360, 648
+    img = _scene(h, w, 77)
+    datas = [_encode(img, quality=80, subsampling=2, restart_marker_blocks=1), _encode(img, quality=70, subsampling=1, restart_marker_blocks=7),
+             _encode(img, quality=90, subsampling=0, restart_marker_rows=1), _encode(img, quality=60, subsampling=2, restart_marker_rows=5),
+             _encode(img[..., 1], quality=85, restart_marker_blocks=13), _encode(img, quality=75, subsampling=1, restart_marker_rows=100),
+             _encode(img, quality=75, subsampling=1)]
+    ctx = _hip.Context(h, w, 8)
+    got = ctx.decode_jpeg(datas)
+    for i, d in enumerate(datas):
+        assert np.array_equal(got[i], orc.jpeg_decode(d)), i
+    # a damaged interval is reported, the others do not hide it
+    bad = bytearray(datas[1])
+    at = bad.index(b"\xff\xd3", bad.index(b"\xff\xda"))
+    bad[at + 1] = 0xD5  # a restart marker out of sequence
+    with pytest.raises(_hip.CamsyncError):
+        ctx.decode_jpeg([bytes(bad)])
+    assert np.array_equal(ctx.decode_jpeg(datas[:1])[0], got[0])
+
+
+@pytest.mark.gpu
 def test_gpu_refuses_what_the_decoder_does_not_take():
     from cameracalibration_amd import _hip
     img = _scene(48, 64, 3)
