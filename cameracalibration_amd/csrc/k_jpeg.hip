@@ -997,7 +997,7 @@ __global__ __launch_bounds__(256) void k_jpeg_color(const uint8_t* __restrict__ 
     }
     const size_t pix = (size_t)f * H * W + (size_t)y * W + x0;
     uint8_t* const o = out + pix * 3;
-    if (x0 + 7 < W && (pix & 7u) == 0) {  // (24 bytes, 8-byte aligned when the pixel index is a multiple of 8: `out` is)
+    if (x0 + 7 < W && (reinterpret_cast<uintptr_t>(o) & 7u) == 0) {  // (24 bytes in three 8-byte stores)
         uint2* o64 = reinterpret_cast<uint2*>(o);
         o64[0] = make_uint2(px[0] | (px[1] << 24), (px[1] >> 8) | (px[2] << 16));
         o64[1] = make_uint2((px[2] >> 16) | (px[3] << 8), px[4] | (px[5] << 24));
