@@ -657,6 +657,7 @@ __global__ __launch_bounds__(256) void k_jpeg_par(const uint8_t* __restrict__ ub
         if (lane == 0) s_red[wave] = part;
         __syncthreads();
         q = s_red[0] + s_red[1] + s_red[2] + s_red[3] + before + inc - mineN;
+        if (i == 0u && nSub == 0u) status[f] = 1;  // no entropy-coded data at all
         if (!valid) return;
     }
     // ---- the decoder's state at the entry ----

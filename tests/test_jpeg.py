@@ -238,7 +238,9 @@ def test_gpu_refuses_what_the_decoder_does_not_take():
     img = _scene(48, 64, 3)
     ctx = _hip.Context(64, 64, 4)
     good = _encode(img, quality=80)
-    for bad in (_encode(img, progressive=True), good[:300], _encode(_scene(40, 64, 1), quality=80)):
+    sos = good.index(b"\xff\xda")
+    empty_scan = good[:sos + 14] + b"\xff\xd9"  # headers, then the end of the image at once
+    for bad in (_encode(img, progressive=True), good[:300], _encode(_scene(40, 64, 1), quality=80), empty_scan):
         with pytest.raises(_hip.CamsyncError) as e:
             ctx.decode_jpeg([good, bad])
         assert e.value.code == _hip.E_ARG
