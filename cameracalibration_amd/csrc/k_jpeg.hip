@@ -867,7 +867,9 @@ __global__ __launch_bounds__(256) void k_jpeg_idct(int16_t* __restrict__ coef, c
     const uint32_t brow = idx / bw, bcol = idx - brow * bw;
     uint4* const cp = reinterpret_cast<uint4*>(coef + ((size_t)f * frameBlocks + slot) * 64 + r * 8);
     const uint4 cv = *cp;
-    *cp = make_uint4(0, 0, 0, 0);  // (the coefficient planes are all zero between calls: k_jpeg_huff stores only what is not)
+    // (the coefficient planes are all zero between calls: the entropy decoders store only what is not; most of a
+    // block's high-frequency pieces are zero already and need no store)
+    if (cv.x | cv.y | cv.z | cv.w) *cp = make_uint4(0, 0, 0, 0);
     const uint4 qv = *reinterpret_cast<const uint4*>(quant + ((size_t)f * 4 + (c == 0 ? d.tq[0] : c == 1 ? d.tq[1] : d.tq[2])) * 64 + r * 8);
     uint32_t cw[4] = {cv.x, cv.y, cv.z, cv.w};
     const uint32_t qw[4] = {qv.x, qv.y, qv.z, qv.w};
