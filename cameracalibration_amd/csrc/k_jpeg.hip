@@ -522,13 +522,16 @@ __global__ __launch_bounds__(64) void k_jpeg_huff_wave(const uint8_t* __restrict
 // k_jpeg_par<true> then decodes every subsequence once more from its true entry state, now knowing (prefix sum of the
 // block counts) which block it is in, and stores the coefficients; DC differences are stored as they are coded and
 // summed per component afterwards (k_jpeg_dc).  One 1080p frame: ~1900 lanes instead of one chain of 350 k symbols.
-// Frames with restart intervals (whose intervals need no guessing: k_jpeg_huff_wave decodes them side by side), and
-// frames whose records have not settled after kParMaxRounds rounds, take the sequential kernels above.
+// Where decoders do not fall into step (flat or periodic stretches, quality-100 frames) the true records still spread
+// one subsequence per round, and a round that nearly every lane leaves at once takes 10-20 us: a frame of n
+// subsequences has settled after n rounds at the latest.  Frames with restart intervals (whose intervals need no
+// guessing: k_jpeg_huff_wave decodes them side by side), and frames whose records have not settled after
+// kParMaxRounds rounds, take the sequential kernels above.
 #ifndef PAR_BITS
 #define PAR_BITS 1024
 #endif
 constexpr uint32_t kParBits = PAR_BITS;  // a multiple of 32
-constexpr int kParMaxRounds = 128;
+constexpr int kParMaxRounds = 3072;
 constexpr unsigned long long kParStateMask = 0xFFFFFFFFFFFFull;  // position | block of the MCU << 32 | coefficient << 40
 
 // One workgroup per frame: the frame's entropy-coded bytes without the stuffed zeros (0xFF 0x00 -> 0xFF), up to the
@@ -1576,17 +1579,21 @@ int jpeg_decode_batch(JpegState* s, hipStream_t st, const uint8_t* const* jpegs,
                                d_ulen, d_subBase, s->d_rec, s->d_last);
             // rounds until one changes nothing; the host only looks after some of them (a round in which few lanes have work
             // is a few microseconds, waiting for the stream is more)
+            // (the true records spread at least one subsequence a round, so a frame of n subsequences has settled after n
+            // rounds at the latest; a round in which nearly every lane finds its entry unchanged takes 10-20 us)
             bool settled = false;
-            static const int kLook[] = {3, 5, 8, 12, 16, 24, 32, 48, 64, 96, kParMaxRounds};
-            int look = 0;
-            for (int round = 1; round <= kParMaxRounds && !settled; round++) {
-                const bool check = round == kLook[look];
+            uint32_t longest = 0;
+            for (int i : parList) longest = std::max(longest, (uint32_t)(((size_t)pf[(size_t)i].d.dataLen * 8 + kParBits - 1) / kParBits));
+            const int maxRounds = (int)std::min<uint32_t>((uint32_t)kParMaxRounds, longest + 1u);
+            int nextLook = std::min(3, maxRounds);
+            for (int round = 1; round <= maxRounds && !settled; round++) {
+                const bool check = round == nextLook;
                 if (check && (e = hipMemsetAsync(s->d_changed, 0, sizeof(int32_t), st)) != hipSuccess) return hipfail("hipMemsetAsync", e);
                 hipLaunchKernelGGL((k_jpeg_par<false>), dim3((unsigned)nWg), dim3(256), 0, st, s->d_ubytes, s->d_desc, d_wgFrame, d_wgFirst,
                                    s->d_tables, d_frameSet, d_ulen, d_subBase, s->d_rec, s->d_last, s->d_changed, round, d_skip, s->d_coef,
                                    s->d_dcs, frameBlocks, s->d_status);
                 if (!check) continue;
-                look++;
+                nextLook = std::min(maxRounds, nextLook + std::max(2, nextLook / 2));
                 int32_t flag = 0;
                 if ((e = hipMemcpyAsync(&flag, s->d_changed, sizeof flag, hipMemcpyDeviceToHost, st)) != hipSuccess) return hipfail("hipMemcpyAsync", e);
                 if ((e = hipStreamSynchronize(st)) != hipSuccess) return hipfail("JPEG kernels (parallel entropy decoding)", e);
@@ -1598,7 +1605,7 @@ int jpeg_decode_batch(JpegState* s, hipStream_t st, const uint8_t* const* jpegs,
                 std::vector<int32_t> last((size_t)nb + 1, 0);
                 if ((e = hipMemcpy(last.data(), s->d_changed, sizeof(int32_t) * ((size_t)nb + 1), hipMemcpyDeviceToHost)) != hipSuccess) return hipfail("hipMemcpy", e);
                 for (int i : parList)
-                    if (last[(size_t)i + 1] == kParMaxRounds) skip[(size_t)i] = 1;
+                    if (last[(size_t)i + 1] == maxRounds) skip[(size_t)i] = 1;
                 if ((e = hipMemcpyAsync(s->d_parMeta + (size_t)2 * nb, skip.data(), (size_t)nb * 4, hipMemcpyHostToDevice, st)) != hipSuccess) return hipfail("hipMemcpyAsync", e);
             }
             hipLaunchKernelGGL((k_jpeg_par<true>), dim3((unsigned)nWg), dim3(256), 0, st, s->d_ubytes, s->d_desc, d_wgFrame, d_wgFirst,
