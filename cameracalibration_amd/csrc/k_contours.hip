@@ -67,8 +67,10 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-constexpr int kStage = 512;  // starts staged per wavefront before a flush
-constexpr int kSeedStage = 256;  // border seeds likewise
+// (3 KB of LDS per wavefront, so that registers, not LDS, bound the waves per CU: 512 / 256 entries 1.72 ms for the
+// start pass of the bench scene, 256 / 128 1.68 ms, 128 / 64 1.95 ms -- a flush is an atomic on one shared counter)
+constexpr int kStage = 256;  // starts staged per wavefront before a flush
+constexpr int kSeedStage = 128;  // border seeds likewise
 
 // word (xw, y) of a block-linear plane, zero outside the plane
 __device__ __forceinline__ uint32_t pw_at(const uint32_t* __restrict__ plane, int WS, int H, int xw, int y) {
