@@ -115,9 +115,12 @@ __device__ __forceinline__ float patch_elem(const GraySrc& src, int W, int H, co
 // kRegDim^2 bytes).  Every lane returns the refined corner.
 __device__ __forceinline__ void refine_corner(const GraySrc& src, int W, int H, float cTx, float cTy, int win, int max_iters,
                                               double eps2, const float* __restrict__ expTab, int lane, float* s_buf,
-                                              uint8_t* s_reg, float& outX, float& outY) {
+                                              uint8_t* s_reg, float* s_et, float& outX, float& outY) {
     const int ww = 2 * win + 1, pw = ww + 2;
-    const float* __restrict__ et = expTab + win * (2 * kMaxWin + 1);
+    // the window's weights (one row of the table) in LDS: the moment loop reads two of them per element
+    __syncthreads();
+    if (lane < ww) s_et[lane] = expTab[win * (2 * kMaxWin + 1) + lane];
+    const float* const et = s_et;
     // (row, column) of this lane's first element and of a step of 64 elements, for the patch and the window
     const int pi0 = lane / pw, pj0 = lane - pi0 * pw, pqi = 64 / pw, pqj = 64 - pqi * pw;
     const int wi0 = lane / ww, wj0 = lane - wi0 * ww, wqi = 64 / ww, wqj = 64 - wqi * ww;
@@ -205,6 +208,7 @@ __global__ __launch_bounds__(64) void k_subpix(const uint8_t* __restrict__ gray,
                                                const float* __restrict__ expTab, DetCfg cfg) {
     __shared__ float s_buf[kMaxPatch * kMaxPatch];
     __shared__ uint8_t s_reg[kRegDim * kRegDim];
+    __shared__ float s_et[64];
     const int lane = threadIdx.x;
     const unsigned int nM = min(ctr->nMarkers, markerCap);
     const int H = cfg.H, W = cfg.W;
@@ -228,7 +232,7 @@ __global__ __launch_bounds__(64) void k_subpix(const uint8_t* __restrict__ gray,
         double eps = fmax(cfg.subpixEps, 0.);
         eps *= eps;
         float cIx, cIy;
-        refine_corner(src, W, H, mc[2 * corner], mc[2 * corner + 1], win, max_iters, eps, expTab, lane, s_buf, s_reg, cIx, cIy);
+        refine_corner(src, W, H, mc[2 * corner], mc[2 * corner + 1], win, max_iters, eps, expTab, lane, s_buf, s_reg, s_et, cIx, cIy);
         if (lane == 0) {
             float* dst = outCorners + ((size_t)mr.frame * cfg.markerOut + mr.slot) * 8;
             dst[2 * corner] = cIx;
@@ -244,6 +248,7 @@ __global__ __launch_bounds__(64) void k_subpix_points(const uint8_t* __restrict_
                                                       float* __restrict__ out) {
     __shared__ float s_buf[kMaxPatch * kMaxPatch];
     __shared__ uint8_t s_reg[kRegDim * kRegDim];
+    __shared__ float s_et[64];
     const int lane = threadIdx.x;
     const unsigned int total = (unsigned int)B * (unsigned int)N;
     for (unsigned int job = blockIdx.x; job < total; job += gridDim.x) {
@@ -251,7 +256,7 @@ __global__ __launch_bounds__(64) void k_subpix_points(const uint8_t* __restrict_
         if (npts && (int)k >= npts[f]) continue;  // (uniform: the whole wave works on one job)
         const GraySrc src{gray + (size_t)f * H * W * grayC, grayC, (uint32_t)(H * W - 1)};
         float cx, cy;
-        refine_corner(src, W, H, pts[2 * (size_t)job], pts[2 * (size_t)job + 1], win, maxIters, eps2, expTab, lane, s_buf, s_reg, cx, cy);
+        refine_corner(src, W, H, pts[2 * (size_t)job], pts[2 * (size_t)job + 1], win, maxIters, eps2, expTab, lane, s_buf, s_reg, s_et, cx, cy);
         if (lane == 0) {
             out[2 * (size_t)job] = cx;
             out[2 * (size_t)job + 1] = cy;
