@@ -240,17 +240,17 @@ def test_gpu_refuses_what_the_decoder_does_not_take():
     good = _encode(img, quality=80)
     sos = good.index(b"\xff\xda")
     empty_scan = good[:sos + 14] + b"\xff\xd9"  # headers, then the end of the image at once
-    for bad in (_encode(img, progressive=True), good[:300], _encode(_scene(40, 64, 1), quality=80), empty_scan):
+    for bad in (_encode(img, progressive=True), good[:300], _encode(_scene(40, 64, 1), quality=80)):
         with pytest.raises(_hip.CamsyncError) as e:
             ctx.decode_jpeg([good, bad])
         assert e.value.code == _hip.E_ARG
     # entropy-coded data cut short or damaged: the marker / end of data feeds zeros (as libjpeg does) or the frame is
     # reported as corrupt; either way the call returns and the context stays usable
-    cut = good[:len(good) // 2]
-    try:
-        ctx.decode_jpeg([cut])
-    except _hip.CamsyncError as e2:
-        assert e2.code == _hip.E_ARG
+    for cut in (good[:len(good) // 2], empty_scan):
+        try:
+            ctx.decode_jpeg([cut])
+        except _hip.CamsyncError as e2:
+            assert e2.code == _hip.E_ARG
     assert np.array_equal(ctx.decode_jpeg([good])[0], orc.jpeg_decode(good))
     # garbled entropy-coded bytes (no new markers), through both Huffman kernels: codes that do not exist, runs past a
     # block's end, a stream that ends early or late
