@@ -270,6 +270,40 @@ def test_gpu_refuses_what_the_decoder_does_not_take():
 
 
 @pytest.mark.gpu
+def test_gpu_compressed_frames_to_poses_without_leaving_the_device():
+    """Ingest feeding the hot path: the reference's photos of the marker sheet (pics/poses, JPEG) are decoded into a
+    device buffer and detection + anchor PnP run on that buffer; ids, corners and poses are those of the same call on
+    the host copies of the decoded frames, and the ids are the oracle's on the oracle's decoding."""
+    import torch
+    from cameracalibration_amd import _hip
+    files = _reference_jpegs()[9:17]
+    datas = [open(f, "rb").read() for f in files]
+    B, H, W = len(datas), 480, 640
+    ctx = _hip.Context(H, W, B)
+    dev = torch.empty((B, H, W, 3), dtype=torch.uint8, device="cuda:0")
+    assert ctx.decode_jpeg(datas, d_bgr_ptr=dev.data_ptr()) == (B, H, W, 3)
+    K, dist = _data.calibration("Logitec_A_1280-720_0.npz")
+    anchors = [10, 11, 14, 15]
+    obj = _data.v1_anchor_points(anchors)
+    MM = 16
+    d_ids = torch.full((B, MM), -1, dtype=torch.int32, device="cuda:0"); d_cor = torch.zeros((B, MM, 4, 2), device="cuda:0")
+    d_cnt = torch.zeros((B,), dtype=torch.int32, device="cuda:0"); d_rv = torch.zeros((B, 3), dtype=torch.float64, device="cuda:0")
+    d_tv = torch.zeros((B, 3), dtype=torch.float64, device="cuda:0"); d_ok = torch.zeros((B,), dtype=torch.uint8, device="cuda:0")
+    ctx.detect_pnp_resident(dev.data_ptr(), B, H, W, 3, anchors, obj, K, dist, MM, d_ids.data_ptr(), d_cor.data_ptr(), d_cnt.data_ptr(),
+                            d_rv.data_ptr(), d_tv.data_ptr(), d_ok.data_ptr())
+    torch.cuda.synchronize()
+    host = ctx.detect_pnp(dev.cpu().numpy(), anchors, obj, K, dist, MM)
+    assert np.array_equal(d_ids.cpu().numpy(), host[0]) and np.array_equal(d_cor.cpu().numpy(), host[1])
+    assert np.array_equal(d_cnt.cpu().numpy(), host[2]) and np.array_equal(d_ok.cpu().numpy(), host[5])
+    assert np.array_equal(d_rv.cpu().numpy(), host[3]) and np.array_equal(d_tv.cpu().numpy(), host[4])
+    for b in range(B):
+        oi, _, _ = orc.detect(orc.jpeg_decode(datas[b]))
+        n = int(host[2][b])
+        assert sorted(host[0][b][:n].tolist()) == sorted(oi.tolist())
+    assert int(host[2].min()) >= 4
+
+
+@pytest.mark.gpu
 def test_camera_takes_pictures_from_an_mjpeg_stream():
     """The mirror's Camera over a stream of MJPEG frames (what a camera in MJPG mode sends): takePic() yields the frames
     cv.VideoCapture.read() would (reference camera.py:150-154), here the reference's own photos of the marker sheet,
