@@ -307,9 +307,34 @@ int upload_host(camsync_ctx* c, const UpSeg* segs, int nseg) {
     // (an upload that goes round the buffer pays for an event per piece: larger pieces then)
     const size_t piece = total > kUpBuffer ? UP_BIG_PIECE * kUpPiece : kUpPiece;
     const size_t slots = kUpBuffer / piece;
-    std::vector<UpSeg> pieces;
-    for (int i = 0; i < nseg; i++)
-        for (size_t o = 0; o < segs[i].n; o += piece) pieces.push_back(UpSeg{segs[i].dst + o, segs[i].src + o, std::min(piece, segs[i].n - o)});
+    // a piece = up to `piece` bytes of consecutive destination: part of a large frame, or many small frames that follow
+    // one another on the device (seg, off: where it starts; n: its bytes)
+    struct Piece { uint8_t* dst; int seg; size_t off, n; };
+    std::vector<Piece> pieces;
+    for (int i = 0; i < nseg;) {
+        size_t o = 0;
+        while (i < nseg) {
+            Piece pc{segs[i].dst + o, i, o, 0};
+            // fill the piece from this segment on, across segments whose destinations are adjacent
+            int j = i;
+            size_t oj = o;
+            while (j < nseg && pc.n < piece) {
+                const size_t take = std::min(piece - pc.n, segs[j].n - oj);
+                pc.n += take;
+                oj += take;
+                if (oj == segs[j].n) {
+                    const bool adjacent = j + 1 < nseg && segs[j + 1].dst == segs[j].dst + segs[j].n;
+                    j++;
+                    oj = 0;
+                    if (!adjacent) break;
+                }
+            }
+            pieces.push_back(pc);
+            i = j;
+            o = oj;
+            if (o == 0) break;
+        }
+    }
     const size_t nP = pieces.size();
     const int T = (int)std::min<size_t>(kUpThreads, nP);
     std::atomic<int> err{(int)hipSuccess};
@@ -320,7 +345,12 @@ int upload_host(camsync_ctx* c, const UpSeg* segs, int nseg) {
             uint8_t* pin = c->upPinned + slot * piece;
             hipError_t e = p >= slots ? hipEventSynchronize(c->upEv[slot]) : hipSuccess;  // the piece sent from this place before
             if (e == hipSuccess) {
-                memcpy(pin, pieces[p].src, pieces[p].n);
+                size_t done = 0, off = pieces[p].off;
+                for (int sg = pieces[p].seg; done < pieces[p].n; sg++, off = 0) {
+                    const size_t take = std::min(pieces[p].n - done, segs[sg].n - off);
+                    memcpy(pin + done, segs[sg].src + off, take);
+                    done += take;
+                }
                 e = hipMemcpyAsync(pieces[p].dst, pin, pieces[p].n, hipMemcpyHostToDevice, c->stream);
             }
             if (e == hipSuccess && p + slots < nP) e = hipEventRecord(c->upEv[slot], c->stream);  // (someone will wait for it)

@@ -335,6 +335,13 @@ def test_host_frames_larger_than_the_upload_buffer_arrive_intact():
     for a, b in zip(ref, sep):
         assert np.array_equal(a, b)
     pinned.close()
+    # many small frames handed over one by one: several of them share a page-locked piece on their way
+    small = [np.ascontiguousarray(frames[i % 12, 200:200 + 96, 300 + (i % 7) * 8:300 + (i % 7) * 8 + 160]) for i in range(420)]
+    ctx2 = _hip.Context(96, 160, 420)
+    a = ctx2.detect_pnp_frames(small, anchors, obj, K, np.zeros(5), 16)
+    b = ctx2.detect_pnp(np.stack(small), anchors, obj, K, np.zeros(5), 16)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
 
 
 def test_fall_back_candidate_when_the_representative_is_no_marker():
